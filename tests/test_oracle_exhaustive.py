@@ -1,0 +1,60 @@
+"""Exhaustive domain checks: every integer shortcut used by the oracle / HIP kernels against the
+literal float formulas of the reference."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+
+from cudacam_amd import synth
+
+KAT = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "survey_kat.json")))
+
+
+def test_direction_all_pairs(oracle):
+    L = oracle.lib()
+    mk, mf = C.c_int(), C.c_int()
+    pairs = np.zeros((64, 2), np.int16)
+    L.orc_check_dir_all(C.byref(mk), C.byref(mf), pairs.ctypes.data_as(C.POINTER(C.c_int16)), 64)
+    assert mk.value == 0                      # kernel form == integer rule on all 4,165,680 pairs
+    got = sorted(map(tuple, pairs[: mf.value].tolist()))
+    assert got == sorted(map(tuple, KAT["direction_float_vs_integer_exceptions_glibc"]))
+
+
+def test_gradient_all_pairs(oracle):
+    assert oracle.lib().orc_check_grad_all() == 0
+
+
+def test_div159_magic():
+    S = np.arange(0, 159 * 255 + 1, dtype=np.uint64)
+    assert np.array_equal((S * np.uint64(52759)) >> np.uint64(23), S // np.uint64(159))
+    assert int(S[-1]) * 52759 < 2 ** 31
+
+
+def test_gaussian_shortcut_random_patches(oracle):
+    L = oracle.lib()
+    L.orc_check_gauss_random.restype = C.c_long
+    nd, nm = C.c_long(), C.c_long()
+    bad = L.orc_check_gauss_random(C.c_ulonglong(0xC0FFEE), C.c_long(20_000_000), C.byref(nd), C.byref(nm))
+    assert bad == 0 and nd.value > 0 and nm.value > nd.value
+
+
+def test_gaussian_shortcut_images(oracle):
+    for img in (synth.noise(321, 123, 7), synth.natural(333, 222, 3), synth.flat(33, 17, 255), synth.flat(20, 20, 0),
+                synth.steps(64, 48, 255, "diagonal")):
+        assert np.array_equal(oracle.gaussian(img, fused=True), oracle.gaussian(img, shortcut=True))
+
+
+def test_threshold_bands_all_S():
+    """nms value = isqrt(S>>2) & 0xFF (the u8 wrap).  `value > T` as interval tests on S -- the form
+    the HIP kernel evaluates with v_cmp masks -- for every reachable S and every T."""
+    S = np.arange(0, 2 * 1020 * 1020 + 1, dtype=np.int64)
+    g = np.floor(np.sqrt((S >> 2).astype(np.float64))).astype(np.int64)
+    g -= (g * g > (S >> 2))
+    g += ((g + 1) * (g + 1) <= (S >> 2))
+    val = g & 0xFF
+    B0, B1 = 4 * 256 * 256, 4 * 512 * 512
+    for T in list(range(0, 256, 5)) + [9, 10, 39, 40, 254, 255]:
+        a0, a1, a2 = 4 * (T + 1) ** 2, 4 * (257 + T) ** 2, 4 * (513 + T) ** 2
+        band = ((S >= a0) & (S < B0)) | ((S >= a1) & (S < B1)) | (S >= a2)
+        assert np.array_equal(band, val > T), T
