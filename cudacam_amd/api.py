@@ -1,0 +1,341 @@
+"""ctypes binding of libhipcanny.so plus Python mirrors of the reference operator classes.
+
+`CannyEdge` and `cvPipeline` keep the names, argument meaning and error behaviour of
+cvp::cuda::CannyEdge (src/cvp/cannyEdgeH.hpp:17-32) and cvp::cvPipeline (src/cvp/cvPipeline.hpp:20-39)
+so the parity tests read like tests of the reference.  numpy arrays play the role of cv::Mat:
+(H, W) uint8 == CV_8UC1, (H, W, 3) uint8 == CV_8UC3 (BGR).
+
+There is no CPU fallback: if the shared library or a GPU is missing, construction raises.
+"""
+import ctypes as C
+import enum
+import os
+import sys
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhipcanny.so")
+
+
+class CannyStage(enum.IntEnum):
+    """cvp::CannyStage, src/cvp/define.hpp:9-17"""
+    MONO = 0
+    GAUSSIAN = 1
+    GRADIENT = 2
+    NMS = 3
+    THRESH = 4
+    HYSTER = 5
+
+
+# cvp::CANNY_STAGES, src/cvp/define.hpp:27-34 (display strings double as timer names)
+CANNY_STAGES = {
+    CannyStage.MONO: "1/6 Mono Conversion",
+    CannyStage.GAUSSIAN: "2/6 Gaussian Noise Removal",
+    CannyStage.GRADIENT: "3/6 Gradient Computation",
+    CannyStage.NMS: "4/6 Non Maximum Suppression",
+    CannyStage.THRESH: "5/6 Double Threshold",
+    CannyStage.HYSTER: "6/6 Hysteresis",
+}
+
+MODE_R, MODE_O = 0, 1
+
+# every symbol include/hipcanny.h declares
+ABI_SYMBOLS = [
+    "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
+    "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms",
+    "hc_device_ptrs", "hc_last_hysteresis_info", "hc_set_tuning", "hc_selftest", "hc_last_error", "hc_version",
+]
+
+_lib = None
+
+
+class HipCannyError(RuntimeError):
+    pass
+
+
+def load_library():
+    """Loads libhipcanny.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipCannyError(f"{LIB_PATH} is missing: run `python -m cudacam_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
+    L.hc_create.restype = vp
+    L.hc_create.argtypes = [i, i, i, i, i, i]
+    L.hc_destroy.restype = None
+    L.hc_destroy.argtypes = [vp]
+    L.hc_set_thresholds.argtypes = [vp, i, i]
+    L.hc_get_thresholds.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.hc_upload.argtypes = [vp, vp, sz, sz, i]
+    L.hc_run.argtypes = [vp, i, i]
+    L.hc_run_device.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i]
+    L.hc_hysteresis_device.argtypes = [vp, vp, sz, sz, vp, sz, sz, i]
+    L.hc_download.argtypes = [vp, vp, sz, sz, i]
+    L.hc_sync.argtypes = [vp]
+    L.hc_set_stream.argtypes = [vp, vp]
+    L.hc_enable_profiling.argtypes = [vp, i]
+    L.hc_stage_time_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
+    L.hc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.hc_last_hysteresis_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.hc_set_tuning.argtypes = [vp, i, i]
+    L.hc_selftest.argtypes = [i]
+    L.hc_last_error.restype = C.c_char_p
+    L.hc_version.restype = C.c_char_p
+    for name in ABI_SYMBOLS:
+        getattr(L, name)
+    _lib = L
+    return L
+
+
+def last_error():
+    return load_library().hc_last_error().decode()
+
+
+def _ck(rc):
+    if rc != 0:
+        raise HipCannyError(f"hipcanny error {rc}: {last_error()}")
+
+
+class Context:
+    """Thin RAII wrapper of hc_ctx (one device, one stream)."""
+
+    def __init__(self, width, height, channels=1, max_batch=1, mode=MODE_R, device=0):
+        self.lib = load_library()
+        self.w, self.h, self.c, self.max_batch = int(width), int(height), int(channels), int(max_batch)
+        self.handle = self.lib.hc_create(int(device), self.w, self.h, self.c, self.max_batch, int(mode))
+        if not self.handle:
+            raise HipCannyError(f"hc_create failed: {last_error()}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.hc_destroy(self.handle)
+            self.handle = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def set_thresholds(self, low, high):
+        _ck(self.lib.hc_set_thresholds(self.handle, int(low), int(high)))
+
+    def get_thresholds(self):
+        lo, hi = C.c_int(), C.c_int()
+        _ck(self.lib.hc_get_thresholds(self.handle, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def set_tuning(self, chunk_rows=0, hyst_launches=4):
+        _ck(self.lib.hc_set_tuning(self.handle, int(chunk_rows), int(hyst_launches)))
+
+    def set_stream(self, stream_handle):
+        _ck(self.lib.hc_set_stream(self.handle, C.c_void_p(stream_handle)))
+
+    def enable_profiling(self, on):
+        _ck(self.lib.hc_enable_profiling(self.handle, int(bool(on))))
+
+    def stage_time_ms(self, stage):
+        ms = C.c_float()
+        _ck(self.lib.hc_stage_time_ms(self.handle, int(stage), C.byref(ms)))
+        return ms.value
+
+    def upload(self, frames):
+        """frames: (n,H,W) / (n,H,W,3) uint8, or a single frame."""
+        a = np.ascontiguousarray(frames, dtype=np.uint8)
+        if a.ndim == (2 if self.c == 1 else 3):
+            a = a[None]
+        exp = (self.h, self.w) if self.c == 1 else (self.h, self.w, 3)
+        if a.shape[1:] != exp:
+            raise HipCannyError(f"Cannot load image to GPU, specs different since initialization: {a.shape[1:]} vs {exp}")
+        row = self.w * self.c
+        _ck(self.lib.hc_upload(self.handle, a.ctypes.data, row, row * self.h, a.shape[0]))
+        self._keep = a
+        return a.shape[0]
+
+    def run(self, final_stage=CannyStage.HYSTER, nframes=1):
+        _ck(self.lib.hc_run(self.handle, int(final_stage), int(nframes)))
+
+    def download(self, nframes=1):
+        out = np.empty((nframes, self.h, self.w), np.uint8)
+        _ck(self.lib.hc_download(self.handle, out.ctypes.data, self.w, self.w * self.h, nframes))
+        return out
+
+    def sync(self):
+        _ck(self.lib.hc_sync(self.handle))
+
+    def run_device(self, d_in, in_pitch, in_fs, d_out, out_pitch, out_fs, nframes, final_stage=CannyStage.HYSTER):
+        _ck(self.lib.hc_run_device(self.handle, C.c_void_p(d_in), in_pitch, in_fs, C.c_void_p(d_out), out_pitch, out_fs,
+                                   int(nframes), int(final_stage)))
+
+    def hysteresis_device(self, d_thr, in_pitch, in_fs, d_out, out_pitch, out_fs, nframes):
+        _ck(self.lib.hc_hysteresis_device(self.handle, C.c_void_p(d_thr), in_pitch, in_fs, C.c_void_p(d_out), out_pitch,
+                                          out_fs, int(nframes)))
+
+    def hysteresis_info(self):
+        a, b = C.c_int(), C.c_int()
+        _ck(self.lib.hc_last_hysteresis_info(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def process(self, frames, final_stage=CannyStage.HYSTER):
+        """upload -> run -> download convenience."""
+        n = self.upload(frames)
+        self.run(final_stage, n)
+        return self.download(n)
+
+
+def selftest(device=0):
+    _ck(load_library().hc_selftest(int(device)))
+
+
+class TimerManager:
+    """timerManager singleton, src/utils/timer.hpp:13-67 (running averages keyed by stage name)."""
+    _inst = None
+
+    def __init__(self):
+        self._timers = {}
+
+    @classmethod
+    def Get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+    def createTimer(self, name):
+        self._timers.setdefault(name, [0.0, 0])
+
+    def addTime(self, name, t):
+        if name in self._timers:
+            self._timers[name][0] += t
+            self._timers[name][1] += 1
+        else:
+            print(f"Timer {name} unknown", file=sys.stderr)
+
+    def getAverageTime(self, name):
+        t = self._timers.get(name)
+        if t and t[1] > 0:
+            return t[0] / t[1]
+        print(f"Timer {name} unknown", file=sys.stderr)
+        return 0.0
+
+    def timers(self):
+        return dict(self._timers)
+
+
+def _mat_type(mat):
+    if not isinstance(mat, np.ndarray) or mat.dtype != np.uint8:
+        return None
+    if mat.ndim == 2:
+        return "CV_8UC1"
+    if mat.ndim == 3 and mat.shape[2] == 3:
+        return "CV_8UC3"
+    return None
+
+
+class CannyEdge:
+    """Mirror of cvp::cuda::CannyEdge (src/cvp/cannyEdgeH.hpp:17-32).
+
+    pbo: the reference's OpenGL pixel-buffer id; a headless MI355X has no GL, so it must be 0 and
+    the result is read with output() instead.
+    """
+
+    def __init__(self, pbo, imageWidth, imageHeight, imageNbChannels, mode=MODE_R, device=0):
+        if pbo != 0:
+            raise HipCannyError("GL interop is not available on MI355X: pass pbo=0 and read output()")
+        self._ctx = Context(imageWidth, imageHeight, imageNbChannels, 1, mode, device)
+        self.m_inputW, self.m_inputH, self.m_inputNbChannels = imageWidth, imageHeight, imageNbChannels
+        self._ctx.set_thresholds(10, 40) if mode == MODE_R else None  # cannyEdgeH.cu:22-23
+        self._profiling = True                                          # cannyEdgeH.cu:24
+        self._ctx.enable_profiling(True)
+        self._out = None
+        tm = TimerManager.Get()
+        for name in CANNY_STAGES.values():                              # cannyEdgeH.cu:35-37
+            tm.createTimer(name)
+
+    def run(self, input, finalStage):
+        """cannyEdgeH.cu:49-120.  Size/channel mismatch: logged, frame not processed (:124-130)."""
+        exp = (self.m_inputH, self.m_inputW) if self.m_inputNbChannels == 1 else (self.m_inputH, self.m_inputW, 3)
+        if input.shape != exp:
+            print("Cannot load image to GPU, specs different since initialization", file=sys.stderr)
+            return
+        try:
+            stage = CannyStage(int(finalStage))
+        except ValueError:
+            print("Canny Stage Not Recognized", file=sys.stderr)
+            return
+        self._ctx.upload(input)
+        self._ctx.run(stage, 1)
+        self._out = self._ctx.download(1)[0]
+        if self._profiling:
+            tm = TimerManager.Get()
+            for st in (CannyStage.MONO, CannyStage.THRESH, CannyStage.HYSTER):
+                tm.addTime(CANNY_STAGES[st], self._ctx.stage_time_ms(st))
+
+    def output(self):
+        return self._out
+
+    def setLowThreshold(self, low):
+        lo, hi = self._ctx.get_thresholds()
+        self._ctx.set_thresholds(min(int(low) & 0xFF, hi), hi)     # cannyEdgeH.hpp:25
+
+    def getLowThreshold(self):
+        return self._ctx.get_thresholds()[0]
+
+    def setHighThreshold(self, high):
+        lo, hi = self._ctx.get_thresholds()
+        self._ctx.set_thresholds(lo, max(int(high) & 0xFF, lo))    # cannyEdgeH.hpp:28
+
+    def getHighThreshold(self):
+        return self._ctx.get_thresholds()[1]
+
+    def enableKernelProfiling(self, profiling):
+        self._profiling = bool(profiling)
+        self._ctx.enable_profiling(self._profiling)
+
+    def isKernelProfilingEnabled(self):
+        return self._profiling
+
+
+class cvPipeline:
+    """Mirror of cvp::cvPipeline (src/cvp/cvPipeline.hpp:20-39, cvPipeline.cpp:9-96)."""
+
+    def __init__(self, pbo, inputImageCols, inputImageRows, inputImageNbChannels, mode=MODE_R, device=0):
+        self.m_cudaCannyEdge = CannyEdge(pbo, inputImageCols, inputImageRows, inputImageNbChannels, mode, device)
+
+    def process(self, inputImage, finalStage):
+        if self.m_cudaCannyEdge is None:
+            print("Cannot process the webcam stream, Cuda is not ready.", file=sys.stderr)
+            return False
+        if inputImage is None or getattr(inputImage, "size", 0) == 0:
+            print("Blank frame grabbed", file=sys.stderr)                       # cvPipeline.cpp:27-31
+            return False
+        if _mat_type(inputImage) is None:
+            print("Only supporting CV_8UC3 and CV_8UC1 input types for now", file=sys.stderr)  # :32-36
+            return False
+        self.m_cudaCannyEdge.run(inputImage, finalStage)
+        return True
+
+    def output(self):
+        return self.m_cudaCannyEdge.output()
+
+    def setLowThreshold(self, low):
+        self.m_cudaCannyEdge.setLowThreshold(low)
+
+    def getLowThreshold(self):
+        return self.m_cudaCannyEdge.getLowThreshold()
+
+    def setHighThreshold(self, high):
+        self.m_cudaCannyEdge.setHighThreshold(high)
+
+    def getHighThreshold(self):
+        return self.m_cudaCannyEdge.getHighThreshold()
+
+    def enableCudaProfiling(self, profiling):
+        self.m_cudaCannyEdge.enableKernelProfiling(profiling)
+
+    def isCudaProfilingEnabled(self):
+        return self.m_cudaCannyEdge.isKernelProfilingEnabled() if self.m_cudaCannyEdge else False

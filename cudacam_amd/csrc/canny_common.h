@@ -1,0 +1,80 @@
+// canny_common.h -- shared declarations of the hipcanny device code and its host launcher.
+// Hand-written for gfx950 (CDNA4, wave64).  Not a translation of the reference's CUDA kernels:
+// see DESIGN.md for the layout (strips, chunks, bit planes) and for why each choice was made.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hc {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// ---- geometry of the fused path ---------------------------------------------------------------
+// A wave owns a vertical STRIP of the frame: lane l holds the 4 adjacent pixels at columns
+// strip*STRIP_W - 4 + 4*l .. +3 of the current row, packed in one dword.  Lanes 0 and 63 are halo
+// lanes (4 px each side = 2 blur + 1 Sobel + 1 NMS), lanes 1..62 produce STRIP_W = 248 outputs.
+constexpr int LANES = 64;
+constexpr int PX_PER_LANE = 4;
+constexpr int STRIP_W = (LANES - 2) * PX_PER_LANE;  // 248
+constexpr int STRIP_HALO = PX_PER_LANE;             // 4 columns = one lane
+
+// Bit-plane record of one (frame, strip, row): 8 x u64.  Word j (0..3): STRONG plane of pixel slot j
+// (bit l <-> column strip*STRIP_W - 4 + 4*l + j); word 4+j: CANDIDATE plane (includes strong).
+// Bits 0 and 63 (the halo lanes) are stored as 0.
+constexpr int BM_WORDS = 8;
+constexpr u64 BM_VALID = 0x7FFFFFFFFFFFFFFEull;
+
+struct FrontParams {
+  const uint8_t *in;       // mono u8 frames, pitched
+  size_t in_pitch;         // bytes per row   (multiple of 4)
+  size_t in_frame_stride;  // bytes per frame (multiple of 4)
+  u64 *bm;                 // bit planes [frame][strip][H][8]
+  int W, H;
+  int nstrips, nchunks, nframes;
+  int total_items;         // nframes * nstrips * nchunks
+  // thresholds on S = sumX^2 + sumY^2 for "u8-wrapped gradient > T" (band test)
+  u32 a_lo[3], a_hi[3];
+};
+
+struct HystParams {
+  u64 *bm;
+  int H, nstrips, nframes;
+  int tile_rows;   // rows per workgroup = 64 * waves
+  int nrtiles;     // ceil(H / tile_rows)
+  u32 *flags;      // flags[k] != 0: launch k changed something another tile can see
+  int iter;        // index of this launch
+};
+
+struct ExpandParams {
+  const u64 *bm;
+  uint8_t *out;
+  size_t out_pitch, out_frame_stride;
+  int W, H, nstrips, nframes;
+};
+
+struct PackParams {  // tri-state u8 map (0/128/255) -> bit planes
+  const uint8_t *in;
+  size_t in_pitch, in_frame_stride;
+  u64 *bm;
+  int W, H, nstrips, nframes;
+};
+
+// ---- host-callable launchers (defined in canny_kernels.hip) -----------------------------------
+hipError_t launch_selftest(u32 *d_result, hipStream_t s);
+hipError_t upload_gauss_coeffs(const float gk[25]);
+hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s);
+hipError_t launch_hyst(const HystParams &p, hipStream_t s);
+hipError_t launch_expand(const ExpandParams &p, hipStream_t s);
+hipError_t launch_pack(const PackParams &p, hipStream_t s);
+size_t front_lds_bytes(int chunk_rows);
+
+// plain per-stage kernels (exact, unfused): the `finalStage` taps MONO..THRESH of CannyEdge::run
+hipError_t launch_gray(const uint8_t *bgr, size_t bpitch, size_t bfs, uint8_t *mono, size_t mpitch, size_t mfs, int W, int H, int n, hipStream_t s);
+hipError_t launch_gauss(const uint8_t *mono, size_t mpitch, size_t mfs, uint8_t *blur, size_t bpitch, size_t bfs, int W, int H, int n, hipStream_t s);
+hipError_t launch_sobel(const uint8_t *blur, size_t bpitch, size_t bfs, int16_t *sx, int16_t *sy, size_t spitch_elems, size_t sfs_elems, int W, int H, int n, hipStream_t s);
+hipError_t launch_graddisp(const int16_t *sx, const int16_t *sy, size_t spitch_elems, size_t sfs_elems, uint8_t *out, size_t opitch, size_t ofs, int W, int H, int n, hipStream_t s);
+hipError_t launch_nms(const int16_t *sx, const int16_t *sy, size_t spitch_elems, size_t sfs_elems, uint8_t *out, size_t opitch, size_t ofs, int W, int H, int n, hipStream_t s);
+hipError_t launch_thresh(const uint8_t *nms, size_t npitch, size_t nfs, uint8_t *out, size_t opitch, size_t ofs, int W, int H, int n, int low, int high, hipStream_t s);
+
+}  // namespace hc

@@ -1,0 +1,478 @@
+// hipcanny.hip -- host side of libhipcanny.so: the C ABI declared in include/hipcanny.h.
+// Replaces the host half of the reference operator (src/cvp/cannyEdgeH.cu): allocation, upload,
+// the stage switch of CannyEdge::run, the hysteresis launch loop and the output copy.
+// There is no CPU fallback anywhere in this file: without a gfx950 device hc_create fails.
+#include "../../include/hipcanny.h"
+#include "canny_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace hc;
+
+namespace {
+thread_local std::string g_err;
+int fail(int code, const std::string &msg)
+{
+  g_err = msg;
+  return code;
+}
+#define HIPCK(expr)                                                                                   \
+  do {                                                                                                \
+    hipError_t e_ = (expr);                                                                           \
+    if (e_ != hipSuccess) return fail(HC_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));  \
+  } while (0)
+
+size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+constexpr int MAX_HYST_LAUNCHES = 16;
+}  // namespace
+
+struct hc_ctx {
+  int device = 0, W = 0, H = 0, C = 1, max_batch = 1, mode = HC_MODE_R;
+  int low = 10, high = 40;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  // internal pitched frames
+  uint8_t *d_in = nullptr, *d_mono = nullptr, *d_out = nullptr;
+  size_t in_pitch = 0, in_fs = 0, mono_pitch = 0, mono_fs = 0, out_pitch = 0, out_fs = 0;
+  // stage-tap scratch (lazy)
+  uint8_t *d_blur = nullptr, *d_nms = nullptr;
+  int16_t *d_sx = nullptr, *d_sy = nullptr;
+  // fused path
+  u64 *d_bm = nullptr;
+  u32 *d_flags = nullptr, *h_flags = nullptr;
+  int nstrips = 0, chunk = 0, hyst_launches = 4, tile_rows = 0, nrtiles = 0;
+  // deferred convergence check of the last fused run
+  bool pending = false;
+  HystParams pend_h{};
+  ExpandParams pend_e{};
+  void *pend_copy_dst = nullptr;  // caller buffer when the expand went to the internal one
+  size_t pend_copy_pitch = 0, pend_copy_fs = 0;
+  int pend_n = 0;
+  int last_work_launches = 0, last_continued = 0;
+  int uploaded = 0, last_run_n = 0;
+  bool profiling = false;
+  hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+  float stage_ms[6] = { 0, 0, 0, 0, 0, 0 };
+  bool ev_valid = false;
+};
+
+namespace {
+
+int alloc_frames(uint8_t **ptr, size_t *pitch, size_t *fs, size_t row_bytes, int H, int n)
+{
+  *pitch = round_up(row_bytes, 256);
+  *fs = *pitch * (size_t)H;
+  HIPCK(hipMalloc((void **)ptr, *fs * (size_t)n));
+  return HC_OK;
+}
+
+int ensure_stage_scratch(hc_ctx *c)
+{
+  if (c->d_blur) return HC_OK;
+  const size_t n = (size_t)c->max_batch;
+  HIPCK(hipMalloc((void **)&c->d_blur, c->out_fs * n));
+  HIPCK(hipMalloc((void **)&c->d_nms, c->out_fs * n));
+  HIPCK(hipMalloc((void **)&c->d_sx, c->out_fs * n * 2));
+  HIPCK(hipMalloc((void **)&c->d_sy, c->out_fs * n * 2));
+  return HC_OK;
+}
+
+bool aligned4(const void *p, size_t a, size_t b) { return (((uintptr_t)p | a | b) & 3u) == 0; }
+
+void band_thresholds(int T, u32 a[3])
+{
+  for (int k = 0; k < 3; ++k) {
+    const u64 g = 256ull * k + (u64)T + 1;
+    a[k] = (u32)std::min<u64>(4ull * g * g, 0xFFFFFFFFull);
+  }
+}
+
+int pick_chunk(const hc_ctx *c, int nframes)
+{
+  if (c->chunk) return c->chunk;
+  // enough waves to fill 256 CUs x 12 wave slots, otherwise shorter chunks (more waves, more halo work)
+  const long waves32 = (long)nframes * c->nstrips * ((c->H + 31) / 32);
+  return waves32 >= 3072 ? 32 : 16;
+}
+
+int copy_frames_d2d(hc_ctx *c, void *dst, size_t dpitch, size_t dfs, const void *src, size_t spitch, size_t sfs, size_t row_bytes, int n)
+{
+  if (dfs == dpitch * (size_t)c->H && sfs == spitch * (size_t)c->H) {
+    HIPCK(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, (size_t)c->H * n, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    for (int f = 0; f < n; ++f)
+      HIPCK(hipMemcpy2DAsync((uint8_t *)dst + dfs * f, dpitch, (const uint8_t *)src + sfs * f, spitch, row_bytes, (size_t)c->H, hipMemcpyDeviceToDevice, c->stream));
+  }
+  return HC_OK;
+}
+
+// Finishes the last fused run: if its queued hysteresis launches did not reach the fixpoint
+// (flag of the last one still set -- adversarial inputs only), keep iterating, then redo the expand.
+int finish_pending(hc_ctx *c)
+{
+  if (!c->pending) return HC_OK;
+  c->pending = false;
+  HIPCK(hipStreamSynchronize(c->stream));
+  const int K = c->hyst_launches;
+  int work = 0;
+  for (int k = 0; k < K; ++k) work += c->h_flags[k] != 0;
+  c->last_work_launches = std::min(K, work + 1);
+  c->last_continued = 0;
+  if (c->h_flags[K - 1] == 0) return HC_OK;
+  c->last_continued = 1;
+  for (int round = 0; round < 1000000; ++round) {
+    HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * MAX_HYST_LAUNCHES, c->stream));
+    HystParams hp = c->pend_h;
+    for (int k = 0; k < K; ++k) {
+      hp.iter = k;
+      HIPCK(launch_hyst(hp, c->stream));
+    }
+    HIPCK(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(u32) * MAX_HYST_LAUNCHES, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipStreamSynchronize(c->stream));
+    for (int k = 0; k < K; ++k) c->last_work_launches += c->h_flags[k] != 0;
+    if (c->h_flags[K - 1] == 0) break;
+  }
+  HIPCK(launch_expand(c->pend_e, c->stream));
+  if (c->pend_copy_dst)
+    if (int rc = copy_frames_d2d(c, c->pend_copy_dst, c->pend_copy_pitch, c->pend_copy_fs, c->pend_e.out, c->pend_e.out_pitch, c->pend_e.out_frame_stride, (size_t)c->W, c->pend_n)) return rc;
+  HIPCK(hipStreamSynchronize(c->stream));
+  return HC_OK;
+}
+
+// bit planes -> fixpoint -> u8 image
+int run_hyst_expand(hc_ctx *c, uint8_t *out, size_t out_pitch, size_t out_fs, int n)
+{
+  const int K = c->hyst_launches;
+  HystParams hp{};
+  hp.bm = c->d_bm; hp.H = c->H; hp.nstrips = c->nstrips; hp.nframes = n; hp.tile_rows = c->tile_rows; hp.nrtiles = c->nrtiles; hp.flags = c->d_flags;
+  for (int k = 0; k < K; ++k) {
+    hp.iter = k;
+    HIPCK(launch_hyst(hp, c->stream));
+  }
+  ExpandParams ep{};
+  ep.bm = c->d_bm; ep.out = out; ep.out_pitch = out_pitch; ep.out_frame_stride = out_fs; ep.W = c->W; ep.H = c->H; ep.nstrips = c->nstrips; ep.nframes = n;
+  HIPCK(launch_expand(ep, c->stream));
+  HIPCK(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(u32) * MAX_HYST_LAUNCHES, hipMemcpyDeviceToHost, c->stream));
+  c->pending = true;
+  c->pend_h = hp;
+  c->pend_e = ep;
+  c->pend_n = n;
+  return HC_OK;
+}
+
+int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_t *out, size_t out_pitch, size_t out_fs, int n, int stage)
+{
+  if (int rc = finish_pending(c)) return rc;
+  if (c->mode != HC_MODE_R) return fail(HC_E_ARG, "mode O is not built into this library version");
+  const int W = c->W, H = c->H;
+  // unaligned caller buffers go through the internal pitched ones
+  const uint8_t *src = in;
+  size_t sp = in_pitch, sfs = in_fs;
+  if (!aligned4(in, in_pitch, in_fs)) {
+    if (int rc = copy_frames_d2d(c, c->d_in, c->in_pitch, c->in_fs, in, in_pitch, in_fs, (size_t)W * c->C, n)) return rc;
+    src = c->d_in; sp = c->in_pitch; sfs = c->in_fs;
+  }
+  uint8_t *dst = out;
+  size_t dp = out_pitch, dfs = out_fs;
+  const bool out_internal = !aligned4(out, out_pitch, out_fs);
+  if (out_internal) { dst = c->d_out; dp = c->out_pitch; dfs = c->out_fs; }
+  c->pend_copy_dst = nullptr;
+
+  if (c->profiling) HIPCK(hipEventRecord(c->ev[0], c->stream));
+  // stage 0 (cannyEdgeH.cu:214-227); 1-channel input skips it (the reference's mono path is broken, SURVEY §3 ii)
+  const uint8_t *mono = src;
+  size_t mp = sp, mfs = sfs;
+  if (c->C == 3) {
+    if (stage == HC_STAGE_MONO) {
+      HIPCK(launch_gray(src, sp, sfs, dst, dp, dfs, W, H, n, c->stream));
+    } else {
+      HIPCK(launch_gray(src, sp, sfs, c->d_mono, c->mono_pitch, c->mono_fs, W, H, n, c->stream));
+      mono = c->d_mono; mp = c->mono_pitch; mfs = c->mono_fs;
+    }
+  } else if (stage == HC_STAGE_MONO) {
+    if (int rc = copy_frames_d2d(c, dst, dp, dfs, src, sp, sfs, (size_t)W, n)) return rc;
+  }
+  if (c->profiling) HIPCK(hipEventRecord(c->ev[1], c->stream));
+
+  if (stage == HC_STAGE_HYSTER) {
+    FrontParams fp{};
+    fp.in = mono; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.bm = c->d_bm; fp.W = W; fp.H = H;
+    const int chunk = pick_chunk(c, n);
+    fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n;
+    fp.total_items = n * fp.nstrips * fp.nchunks;
+    band_thresholds(c->low, fp.a_lo);
+    band_thresholds(c->high, fp.a_hi);
+    HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * MAX_HYST_LAUNCHES, c->stream));
+    HIPCK(launch_front(fp, chunk, c->stream));
+    if (c->profiling) HIPCK(hipEventRecord(c->ev[2], c->stream));
+    if (int rc = run_hyst_expand(c, dst, dp, dfs, n)) return rc;
+  } else if (stage > HC_STAGE_MONO) {
+    if (int rc = ensure_stage_scratch(c)) return rc;
+    const size_t bp = c->out_pitch, bfs = c->out_fs;  // scratch planes share the output geometry
+    uint8_t *blur = stage == HC_STAGE_GAUSSIAN ? dst : c->d_blur;
+    const size_t blp = stage == HC_STAGE_GAUSSIAN ? dp : bp, blfs = stage == HC_STAGE_GAUSSIAN ? dfs : bfs;
+    HIPCK(launch_gauss(mono, mp, mfs, blur, blp, blfs, W, H, n, c->stream));
+    if (stage >= HC_STAGE_GRADIENT) {
+      HIPCK(launch_sobel(blur, blp, blfs, c->d_sx, c->d_sy, bp, bfs, W, H, n, c->stream));
+      if (stage == HC_STAGE_GRADIENT) HIPCK(launch_graddisp(c->d_sx, c->d_sy, bp, bfs, dst, dp, dfs, W, H, n, c->stream));
+      else {
+        uint8_t *nms = stage == HC_STAGE_NMS ? dst : c->d_nms;
+        const size_t np = stage == HC_STAGE_NMS ? dp : bp, nfs = stage == HC_STAGE_NMS ? dfs : bfs;
+        HIPCK(launch_nms(c->d_sx, c->d_sy, bp, bfs, nms, np, nfs, W, H, n, c->stream));
+        if (stage == HC_STAGE_THRESH) HIPCK(launch_thresh(nms, np, nfs, dst, dp, dfs, W, H, n, c->low, c->high, c->stream));
+      }
+    }
+    if (c->profiling) HIPCK(hipEventRecord(c->ev[2], c->stream));
+  } else if (c->profiling) HIPCK(hipEventRecord(c->ev[2], c->stream));
+  if (c->profiling) { HIPCK(hipEventRecord(c->ev[3], c->stream)); c->ev_valid = true; }
+
+  if (out_internal) {
+    if (int rc = copy_frames_d2d(c, out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)W, n)) return rc;
+    if (c->pending) { c->pend_copy_dst = out; c->pend_copy_pitch = out_pitch; c->pend_copy_fs = out_fs; }
+  }
+  c->last_run_n = n;
+  return HC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *hc_last_error(void) { return g_err.c_str(); }
+const char *hc_version(void) { return "hipcanny 0.1 (gfx950)"; }
+
+hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch, int mode)
+{
+  if (width <= 0 || height <= 0 || (channels != 1 && channels != 3) || max_batch <= 0 || (mode != HC_MODE_R && mode != HC_MODE_O)) {
+    fail(HC_E_ARG, "hc_create: bad width/height/channels/max_batch/mode");
+    return nullptr;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    fail(HC_E_NOGPU, "hc_create: no HIP device (this library has no CPU fallback)");
+    return nullptr;
+  }
+  if (hipSetDevice(device) != hipSuccess) { fail(HC_E_HIP, "hipSetDevice failed"); return nullptr; }
+  hc_ctx *c = new hc_ctx();
+  c->device = device; c->W = width; c->H = height; c->C = channels; c->max_batch = max_batch; c->mode = mode;
+  if (mode == HC_MODE_O) { c->low = 50; c->high = 150; }
+  c->nstrips = (width + STRIP_W - 1) / STRIP_W;
+  const int ntiles = (height + 1023) / 1024;
+  const int rows_per = (height + ntiles - 1) / ntiles;
+  c->tile_rows = (int)round_up((size_t)rows_per, 64);
+  c->nrtiles = (height + c->tile_rows - 1) / c->tile_rows;
+  auto ok = [&](hipError_t e, const char *what) {
+    if (e == hipSuccess) return true;
+    fail(HC_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+    return false;
+  };
+  bool good = ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+  c->stream = c->own_stream;
+  good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, (size_t)width * channels, height, max_batch) == HC_OK;
+  good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch) == HC_OK;
+  if (good && channels == 3) good = alloc_frames(&c->d_mono, &c->mono_pitch, &c->mono_fs, (size_t)width, height, max_batch) == HC_OK;
+  good = good && ok(hipMalloc((void **)&c->d_bm, sizeof(u64) * BM_WORDS * (size_t)height * c->nstrips * max_batch), "hipMalloc(bit planes)");
+  good = good && ok(hipMalloc((void **)&c->d_flags, sizeof(u32) * MAX_HYST_LAUNCHES), "hipMalloc(flags)");
+  good = good && ok(hipHostMalloc((void **)&c->h_flags, sizeof(u32) * MAX_HYST_LAUNCHES, hipHostMallocDefault), "hipHostMalloc(flags)");
+  for (int i = 0; good && i < 4; ++i) good = ok(hipEventCreate(&c->ev[i]), "hipEventCreate");
+  if (good) {
+    // cannyEdgeH.cu:372-380: float coefficients K * (1 / 159.0f), computed in binary32 on the host
+    float gk[25];
+    static const int K[25] = { 2, 4, 5, 4, 2, 4, 9, 12, 9, 4, 5, 12, 15, 12, 5, 4, 9, 12, 9, 4, 2, 4, 5, 4, 2 };
+    volatile float r = 1 / 159.0f;
+    for (int i = 0; i < 25; ++i) { volatile float k = (float)K[i]; volatile float v = k * r; gk[i] = v; }
+    good = ok(upload_gauss_coeffs(gk), "hipMemcpyToSymbol(GK)");
+  }
+  if (!good) { hc_destroy(c); return nullptr; }
+  return c;
+}
+
+void hc_destroy(hc_ctx *c)
+{
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
+  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_bm, (void *)c->d_flags }) (void)hipFree(q);
+  if (c->h_flags) (void)hipHostFree(c->h_flags);
+  for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+int hc_set_thresholds(hc_ctx *c, int low, int high)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  low = std::max(0, std::min(255, low));
+  high = std::max(0, std::min(255, high));
+  if (low > high) std::swap(low, high);
+  c->low = low; c->high = high;
+  return HC_OK;
+}
+
+int hc_get_thresholds(const hc_ctx *c, int *low, int *high)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (low) *low = c->low;
+  if (high) *high = c->high;
+  return HC_OK;
+}
+
+int hc_set_stream(hc_ctx *c, void *s)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (int rc = finish_pending(c)) return rc;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return HC_OK;
+}
+
+int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (chunk_rows != 0 && chunk_rows != 16 && chunk_rows != 32 && chunk_rows != 64) return fail(HC_E_ARG, "chunk_rows must be 0, 16, 32 or 64");
+  if (hyst_launches < 1 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range");
+  if (int rc = finish_pending(c)) return rc;
+  c->chunk = chunk_rows; c->hyst_launches = hyst_launches;
+  return HC_OK;
+}
+
+int hc_upload(hc_ctx *c, const uint8_t *host, size_t row_stride, size_t frame_stride, int n)
+{
+  if (!c || !host) return fail(HC_E_ARG, "hc_upload: null argument");
+  if (n <= 0 || n > c->max_batch) return fail(HC_E_ARG, "hc_upload: nframes out of range");
+  const size_t rb = (size_t)c->W * c->C;
+  if (row_stride < rb) return fail(HC_E_ARG, "hc_upload: row_stride smaller than a row");
+  if (int rc = finish_pending(c)) return rc;
+  HIPCK(hipSetDevice(c->device));
+  for (int f = 0; f < n; ++f)  // cannyEdgeH.cu:136/144 (cudaMemcpy2D host -> pitched device)
+    HIPCK(hipMemcpy2DAsync(c->d_in + c->in_fs * f, c->in_pitch, host + frame_stride * f, row_stride, rb, (size_t)c->H, hipMemcpyHostToDevice, c->stream));
+  c->uploaded = n;
+  return HC_OK;
+}
+
+int hc_run(hc_ctx *c, int final_stage, int n)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (final_stage < HC_STAGE_MONO || final_stage > HC_STAGE_HYSTER) return fail(HC_E_ARG, "Canny Stage Not Recognized");
+  if (n <= 0 || n > c->uploaded) return fail(HC_E_STATE, "hc_run: more frames than uploaded");
+  HIPCK(hipSetDevice(c->device));
+  return run_impl(c, c->d_in, c->in_pitch, c->in_fs, c->d_out, c->out_pitch, c->out_fs, n, final_stage);
+}
+
+int hc_run_device(hc_ctx *c, const void *d_in, size_t in_pitch, size_t in_fs, void *d_out, size_t out_pitch, size_t out_fs, int n, int final_stage)
+{
+  if (!c || !d_in || !d_out) return fail(HC_E_ARG, "hc_run_device: null argument");
+  if (final_stage < HC_STAGE_MONO || final_stage > HC_STAGE_HYSTER) return fail(HC_E_ARG, "Canny Stage Not Recognized");
+  if (n <= 0 || n > c->max_batch) return fail(HC_E_ARG, "hc_run_device: nframes out of range");
+  if (in_pitch < (size_t)c->W * c->C || out_pitch < (size_t)c->W) return fail(HC_E_ARG, "hc_run_device: pitch smaller than a row");
+  HIPCK(hipSetDevice(c->device));
+  return run_impl(c, (const uint8_t *)d_in, in_pitch, in_fs, (uint8_t *)d_out, out_pitch, out_fs, n, final_stage);
+}
+
+int hc_hysteresis_device(hc_ctx *c, const void *d_thresh, size_t in_pitch, size_t in_fs, void *d_out, size_t out_pitch, size_t out_fs, int n)
+{
+  if (!c || !d_thresh || !d_out) return fail(HC_E_ARG, "hc_hysteresis_device: null argument");
+  if (n <= 0 || n > c->max_batch) return fail(HC_E_ARG, "hc_hysteresis_device: nframes out of range");
+  HIPCK(hipSetDevice(c->device));
+  if (int rc = finish_pending(c)) return rc;
+  PackParams pp{};
+  pp.in = (const uint8_t *)d_thresh; pp.in_pitch = in_pitch; pp.in_frame_stride = in_fs; pp.bm = c->d_bm; pp.W = c->W; pp.H = c->H; pp.nstrips = c->nstrips; pp.nframes = n;
+  HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * MAX_HYST_LAUNCHES, c->stream));
+  HIPCK(launch_pack(pp, c->stream));
+  uint8_t *dst = (uint8_t *)d_out;
+  size_t dp = out_pitch, dfs = out_fs;
+  const bool out_internal = !aligned4(d_out, out_pitch, out_fs);
+  if (out_internal) { dst = c->d_out; dp = c->out_pitch; dfs = c->out_fs; }
+  c->pend_copy_dst = nullptr;
+  if (int rc = run_hyst_expand(c, dst, dp, dfs, n)) return rc;
+  if (out_internal) {
+    if (int rc = copy_frames_d2d(c, d_out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)c->W, n)) return rc;
+    c->pend_copy_dst = d_out; c->pend_copy_pitch = out_pitch; c->pend_copy_fs = out_fs;
+  }
+  return HC_OK;
+}
+
+int hc_sync(hc_ctx *c)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  HIPCK(hipSetDevice(c->device));
+  if (int rc = finish_pending(c)) return rc;
+  HIPCK(hipStreamSynchronize(c->stream));
+  if (c->profiling && c->ev_valid) {
+    float a = 0, b = 0, d = 0;
+    HIPCK(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
+    HIPCK(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
+    HIPCK(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
+    for (float &m : c->stage_ms) m = 0;
+    c->stage_ms[HC_STAGE_MONO] = a;
+    c->stage_ms[HC_STAGE_THRESH] = b;
+    c->stage_ms[HC_STAGE_HYSTER] = d;
+    c->ev_valid = false;
+  }
+  return HC_OK;
+}
+
+int hc_download(hc_ctx *c, uint8_t *host, size_t row_stride, size_t frame_stride, int n)
+{
+  if (!c || !host) return fail(HC_E_ARG, "hc_download: null argument");
+  if (n <= 0 || n > c->last_run_n) return fail(HC_E_STATE, "hc_download: more frames than the last run produced");
+  if (row_stride < (size_t)c->W) return fail(HC_E_ARG, "hc_download: row_stride smaller than a row");
+  if (int rc = hc_sync(c)) return rc;
+  for (int f = 0; f < n; ++f)
+    HIPCK(hipMemcpy2DAsync(host + frame_stride * f, row_stride, c->d_out + c->out_fs * f, c->out_pitch, (size_t)c->W, (size_t)c->H, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipStreamSynchronize(c->stream));
+  return HC_OK;
+}
+
+int hc_enable_profiling(hc_ctx *c, int on)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  c->profiling = on != 0;
+  return HC_OK;
+}
+
+int hc_stage_time_ms(hc_ctx *c, int stage, float *ms)
+{
+  if (!c || !ms || stage < 0 || stage > 5) return fail(HC_E_ARG, "hc_stage_time_ms: bad argument");
+  *ms = c->stage_ms[stage];
+  return HC_OK;
+}
+
+int hc_device_ptrs(hc_ctx *c, void **d_in, void **d_out, size_t *in_pitch, size_t *out_pitch, size_t *in_fs, size_t *out_fs)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (d_in) *d_in = c->d_in;
+  if (d_out) *d_out = c->d_out;
+  if (in_pitch) *in_pitch = c->in_pitch;
+  if (out_pitch) *out_pitch = c->out_pitch;
+  if (in_fs) *in_fs = c->in_fs;
+  if (out_fs) *out_fs = c->out_fs;
+  return HC_OK;
+}
+
+int hc_last_hysteresis_info(hc_ctx *c, int *launches_with_work, int *continued)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (int rc = finish_pending(c)) return rc;
+  if (launches_with_work) *launches_with_work = c->last_work_launches;
+  if (continued) *continued = c->last_continued;
+  return HC_OK;
+}
+
+int hc_selftest(int device)
+{
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return fail(HC_E_NOGPU, "hc_selftest: no HIP device");
+  HIPCK(hipSetDevice(device));
+  u32 *d = nullptr, h = 0xFFFFFFFFu;
+  HIPCK(hipMalloc((void **)&d, sizeof(u32)));
+  HIPCK(hipMemset(d, 0, sizeof(u32)));
+  HIPCK(launch_selftest(d, nullptr));
+  HIPCK(hipMemcpy(&h, d, sizeof(u32), hipMemcpyDeviceToHost));
+  (void)hipFree(d);
+  if (h) return fail(HC_E_HIP, "hc_selftest: primitive check failed, bits=" + std::to_string(h));
+  return HC_OK;
+}
+}  // extern "C"

@@ -1,0 +1,114 @@
+/*
+ * hipcanny.h -- C ABI of libhipcanny.so: the MI355X (gfx950) Canny edge detector that replaces
+ * the CUDA hot path of axoloto/CudaCam (class cvp::cuda::CannyEdge).
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the CudaCam
+ * tree).  The C++ drop-in classes in include/cvp/ (cvp::cvPipeline, cvp::cuda::CannyEdge) and the
+ * Python binding in cudacam_amd/ are thin layers over exactly these functions.  No torch / HIP
+ * types appear in the signatures: device pointers and streams travel as void*.
+ *
+ * Threading: one context = one device + one stream; a context is not thread-safe, different
+ * contexts may be used from different threads (reference: single-threaded, default stream,
+ * src/imgui/imguiApp.cpp:496-522).
+ * Errors: 0 = ok, negative = failure (see HC_E_*); hc_last_error() returns a message.  The
+ * reference logs and exits the process instead (src/cvp/helper.hpp:4-17).
+ */
+#ifndef HIPCANNY_H
+#define HIPCANNY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hc_ctx hc_ctx;
+
+/* Stage ids: cvp::CannyStage, src/cvp/define.hpp:9-17 */
+enum { HC_STAGE_MONO = 0, HC_STAGE_GAUSSIAN = 1, HC_STAGE_GRADIENT = 2, HC_STAGE_NMS = 3, HC_STAGE_THRESH = 4, HC_STAGE_HYSTER = 5 };
+
+/* Parity modes.  R: bit-exact with the reference kernels (src/cvp/cannyEdgeD.cu).
+ * O: bit-exact with OpenCV cv::Canny(img, low, high, 3, L2gradient=false) (no blur, replicate border). */
+enum { HC_MODE_R = 0, HC_MODE_O = 1 };
+
+enum {
+  HC_OK = 0,
+  HC_E_ARG = -1,      /* bad argument (null, size/channel mismatch, unsupported type) */
+  HC_E_HIP = -2,      /* a HIP runtime call failed (hc_last_error() has the hipError string) */
+  HC_E_STATE = -3,    /* call sequence error (e.g. run before upload) */
+  HC_E_NOGPU = -4     /* no usable gfx950 device */
+};
+
+/* Replaces CannyEdge::CannyEdge + _initAlloc (src/cvp/cannyEdgeH.cu:16-38, 340-385).
+ * width/height/channels as in the reference constructor; max_batch frames can be resident and
+ * processed per hc_run (the reference is single-frame: max_batch = 1).  Defaults follow
+ * cannyEdgeH.cu:22-24: low = 10, high = 40 (Mode O: 50/150).  Returns NULL on failure. */
+hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch, int mode);
+
+/* Replaces CannyEdge::~CannyEdge + _endAlloc (cannyEdgeH.cu:40-47, 387-407). */
+void hc_destroy(hc_ctx *ctx);
+
+/* Replaces setLowThreshold/setHighThreshold (src/cvp/cannyEdgeH.hpp:25-29): the pair is stored as
+ * given after clamping to 0..255 (Mode R) and ordering low <= high. */
+int hc_set_thresholds(hc_ctx *ctx, int low, int high);
+int hc_get_thresholds(const hc_ctx *ctx, int *low, int *high);
+
+/* Replaces _loadInputImage (cannyEdgeH.cu:122-152): host frames -> device.  row_stride = cv::Mat::step,
+ * frame_stride = bytes between consecutive frames.  Asynchronous on the context stream when the
+ * host memory is pinned. */
+int hc_upload(hc_ctx *ctx, const uint8_t *host, size_t row_stride, size_t frame_stride, int nframes);
+
+/* Replaces CannyEdge::run's stage switch (cannyEdgeH.cu:49-120) for the frames last uploaded:
+ * runs the pipeline up to final_stage and leaves that stage's u8 image in the output buffer
+ * (what _sendOutputToOpenGL copies into the PBO, cannyEdgeH.cu:154-212).  Asynchronous. */
+int hc_run(hc_ctx *ctx, int final_stage, int nframes);
+
+/* The same on caller-owned device memory (no upload/download): `d_in` holds nframes frames of
+ * width*channels bytes per row, `d_out` receives nframes tight-or-pitched u8 images.  Pointers,
+ * pitches and frame strides must be multiples of 4 bytes.  Asynchronous on the context stream. */
+int hc_run_device(hc_ctx *ctx, const void *d_in, size_t in_pitch, size_t in_frame_stride, void *d_out, size_t out_pitch,
+                  size_t out_frame_stride, int nframes, int final_stage);
+
+/* The hysteresis stage alone (kernels `hysteresis` + `removeCandidates`, src/cvp/cannyEdgeD.cu:295-395,
+ * loop of cannyEdgeH.cu:297-338) on device tri-state maps (0 / 128 / 255) -> 0 / 255. */
+int hc_hysteresis_device(hc_ctx *ctx, const void *d_thresh, size_t in_pitch, size_t in_frame_stride, void *d_out, size_t out_pitch,
+                         size_t out_frame_stride, int nframes);
+
+/* Device -> host copy of the output images of the last hc_run (the reference leaves them in the
+ * GL PBO; a headless MI355X has no GL: this is the generalised sink). Synchronises. */
+int hc_download(hc_ctx *ctx, uint8_t *host, size_t row_stride, size_t frame_stride, int nframes);
+
+/* Waits for the context stream; also completes the rare hysteresis continuation. */
+int hc_sync(hc_ctx *ctx);
+
+/* Use an external HIP stream (e.g. torch's current stream) instead of the context's own. NULL restores it. */
+int hc_set_stream(hc_ctx *ctx, void *hip_stream);
+
+/* Replaces enableKernelProfiling / _startCudaTimer / _endCudaTimer (cannyEdgeH.hpp:31-32,
+ * cannyEdgeH.cu:409-430): when enabled, hc_run records hipEvents per stage group; hc_stage_time_ms
+ * returns the last run's time attributed to `stage` (the fused kernel's time is reported under
+ * HC_STAGE_THRESH, hysteresis under HC_STAGE_HYSTER).  Off by default on the batch path. */
+int hc_enable_profiling(hc_ctx *ctx, int on);
+int hc_stage_time_ms(hc_ctx *ctx, int stage, float *ms);
+
+/* Internal device buffers (input frames, output images) and their pitch / frame stride. */
+int hc_device_ptrs(hc_ctx *ctx, void **d_in, void **d_out, size_t *in_pitch, size_t *out_pitch, size_t *in_frame_stride,
+                   size_t *out_frame_stride);
+
+/* Number of hysteresis launches that did work in the last run, and whether the continuation ran. */
+int hc_last_hysteresis_info(hc_ctx *ctx, int *launches_with_work, int *continued);
+
+/* Tuning knobs (rows per fused work item: 0 = auto; hysteresis launches queued per run). */
+int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
+
+/* Device self-test of the cross-lane / packed-math primitives the kernels rely on. 0 = ok. */
+int hc_selftest(int device);
+
+const char *hc_last_error(void);
+const char *hc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

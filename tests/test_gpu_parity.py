@@ -1,0 +1,154 @@
+"""GPU parity tests (run on the MI355X box with -m gpu): the HIP path, called through the C ABI,
+against the CPU oracle -- bit-exact, every stage and the final edge map."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from cudacam_amd import api, synth
+
+pytestmark = pytest.mark.gpu
+
+STAGE_KEYS = {
+    api.CannyStage.MONO: "mono", api.CannyStage.GAUSSIAN: "blur", api.CannyStage.GRADIENT: "grad_disp",
+    api.CannyStage.NMS: "nms", api.CannyStage.THRESH: "thresh", api.CannyStage.HYSTER: "edges",
+}
+
+
+def _diff(a, b, what):
+    if np.array_equal(a, b):
+        return
+    bad = np.argwhere(a != b)
+    first = [(tuple(int(v) for v in p), int(a[tuple(p)]), int(b[tuple(p)])) for p in bad[:8]]
+    raise AssertionError(f"{what}: {len(bad)} of {a.size} differ; first (pos, hip, oracle): {first}")
+
+
+def _images():
+    yield "natural_640x480", synth.natural(640, 480, 1)
+    yield "noise_641x479", synth.noise(641, 479, 2)
+    yield "natural_31x33", synth.natural(31, 33, 3)
+    yield "noise_5x5", synth.noise(5, 5, 4)
+    yield "one_px", np.array([[200]], np.uint8)
+    yield "flat100_40x36", synth.flat(40, 36, 100)
+    yield "flat255_300x70", synth.flat(300, 70, 255)
+    yield "zeros_64x64", synth.flat(64, 64, 0)
+    yield "step255_v", synth.steps(260, 64, 255, "vertical")
+    yield "step240_h", synth.steps(100, 90, 240, "horizontal")
+    yield "step234_d", synth.steps(250, 250, 234, "diagonal")
+    yield "serpentine_500x300", synth.serpentine(500, 300)
+    yield "natural_249x17", synth.natural(249, 17, 5)
+    yield "natural_248x65", synth.natural(248, 65, 6)
+    yield "noise_497x130", synth.noise(497, 130, 7)
+
+
+def test_selftest():
+    api.selftest(0)
+
+
+@pytest.mark.parametrize("name,img", list(_images()), ids=[n for n, _ in _images()])
+def test_all_stages_mono(oracle, name, img):
+    h, w = img.shape
+    want = oracle.canny_r(img, 10, 40, stages=True)
+    with api.Context(w, h, 1, 1) as ctx:
+        for stage, key in STAGE_KEYS.items():
+            got = ctx.process(img, stage)[0]
+            _diff(got, want[key], f"{name} stage {stage.name}")
+
+
+@pytest.mark.parametrize("chunk", [16, 32, 64])
+def test_chunk_invariance(oracle, chunk):
+    img = synth.natural(700, 333, 11)
+    want = oracle.canny_r(img, 10, 40)
+    with api.Context(700, 333, 1, 1) as ctx:
+        ctx.set_tuning(chunk, 4)
+        _diff(ctx.process(img)[0], want, f"chunk {chunk}")
+
+
+def test_bgr_input(oracle):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (120, 333, 3), dtype=np.uint8)
+    want = oracle.canny_r(img, 10, 40, stages=True)
+    with api.Context(333, 120, 3, 1) as ctx:
+        for stage, key in STAGE_KEYS.items():
+            _diff(ctx.process(img, stage)[0], want[key], f"bgr stage {stage.name}")
+
+
+@pytest.mark.parametrize("low,high", [(0, 0), (0, 255), (255, 255), (5, 250), (40, 10), (100, 101)])
+def test_thresholds(oracle, low, high):
+    img = synth.steps(300, 200, 250, "diagonal")
+    img[50:150, 40:140] = synth.natural(100, 100, 9)
+    with api.Context(300, 200, 1, 1) as ctx:
+        ctx.set_thresholds(low, high)
+        lo, hi = ctx.get_thresholds()
+        assert (lo, hi) == (min(low, high), max(low, high))
+        want = oracle.canny_r(img, lo, hi, stages=True)
+        _diff(ctx.process(img, api.CannyStage.THRESH)[0], want["thresh"], "thresh")
+        _diff(ctx.process(img, api.CannyStage.HYSTER)[0], want["edges"], "edges")
+
+
+def test_batch_1080p(oracle):
+    frames = np.stack([synth.natural(1920, 1080, 100 + i) for i in range(3)] + [synth.noise(1920, 1080, 200)])
+    want = oracle.canny_r_batch(frames, 10, 40, threads=8)
+    with api.Context(1920, 1080, 1, 4) as ctx:
+        got = ctx.process(frames)
+        for f in range(4):
+            _diff(got[f], want[f], f"1080p frame {f}")
+        assert ctx.hysteresis_info()[0] >= 1
+
+
+def test_hysteresis_device_adversarial(oracle):
+    import torch
+    cases = {
+        "serpentine_300x200": synth.thresh_map_serpentine(300, 200),
+        "serpentine_1000x1100": synth.thresh_map_serpentine(1000, 1100),
+        "random_dense": synth.thresh_map_random(777, 555, 3, 0.45, 0.002),
+        "random_sparse": synth.thresh_map_random(1920, 1080, 4, 0.30, 0.0005),
+        "all_candidates_one_seed": np.full((130, 520), 128, np.uint8),
+    }
+    cases["all_candidates_one_seed"][129, 519] = 255
+    for name, t in cases.items():
+        h, w = t.shape
+        want = oracle.hysteresis(t)
+        pitch = (w + 3) // 4 * 4
+        buf = np.zeros((h, pitch), np.uint8)
+        buf[:, :w] = t
+        d_in = torch.from_numpy(buf).cuda()
+        d_out = torch.zeros((h, pitch), dtype=torch.uint8, device="cuda")
+        with api.Context(w, h, 1, 1) as ctx:
+            ctx.hysteresis_device(d_in.data_ptr(), pitch, pitch * h, d_out.data_ptr(), pitch, pitch * h, 1)
+            ctx.sync()
+            got = d_out.cpu().numpy()[:, :w]
+            _diff(got, want, name)
+            work, cont = ctx.hysteresis_info()
+            assert work >= 1
+            if name.startswith("serpentine_1000"):
+                assert cont == 1  # needs far more cross-tile rounds than the queued launches
+
+
+def test_run_device_unaligned_and_torch_stream(oracle):
+    import torch
+    img = synth.natural(641, 479, 21)
+    want = oracle.canny_r(img, 10, 40)
+    d_in = torch.from_numpy(img).cuda()           # tight pitch 641: not a multiple of 4
+    d_out = torch.zeros_like(d_in)
+    with api.Context(641, 479, 1, 1) as ctx:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        ctx.run_device(d_in.data_ptr(), 641, 641 * 479, d_out.data_ptr(), 641, 641 * 479, 1)
+        ctx.sync()
+        _diff(d_out.cpu().numpy(), want, "unaligned run_device")
+
+
+def test_python_mirror_of_reference_operator(oracle):
+    img = synth.natural(320, 200, 31)
+    pipe = api.cvPipeline(0, 320, 200, 1)
+    assert pipe.getLowThreshold() == 10 and pipe.getHighThreshold() == 40 and pipe.isCudaProfilingEnabled()
+    assert pipe.process(img, api.CannyStage.HYSTER) is True
+    _diff(pipe.output(), oracle.canny_r(img, 10, 40), "cvPipeline.process")
+    assert pipe.process(np.zeros((0, 0), np.uint8), api.CannyStage.HYSTER) is False           # blank frame
+    assert pipe.process(np.zeros((200, 320), np.float32), api.CannyStage.HYSTER) is False     # wrong type
+    pipe.setLowThreshold(90)      # min(low, high) -> 40 (cannyEdgeH.hpp:25)
+    assert pipe.getLowThreshold() == 40
+    pipe.setHighThreshold(5)      # max(high, low) -> 40
+    assert pipe.getHighThreshold() == 40
+    assert api.TimerManager.Get().getAverageTime(api.CANNY_STAGES[api.CannyStage.HYSTER]) >= 0.0
