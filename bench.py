@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hipcanny hot path (see BASELINE.json / SURVEY.md §8d).
+
+A "step" is one pass of the full Canny pipeline (Mode R, thresholds 10/40, final stage HYSTER)
+over one batch of device-resident synthetic 1080p grayscale frames, through the C ABI
+(hc_run_device).  `value` = frames/s of the whole job (all ranks), inputs already in HBM.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Frames shard over ranks with no data-path collective (independent frames): weak
+scaling, one context + one stream per device; torch.distributed only carries the barrier and the
+MAX-reduce of the timing.  torch is plumbing here: device memory, stream, rendezvous.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cudacam_amd import api, synth  # noqa: E402
+
+W, H = 1920, 1080
+LOW, HIGH = 10, 40
+HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_COPY_GBPS = 6290.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
+    ap.add_argument("--chunk", type=int, default=0)
+    ap.add_argument("--hyst-launches", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU baseline sample (0 = auto)")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    api.preload_hip_runtime()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B = a.batch
+    uniq = synth.frames(a.kind, W, H, min(a.unique, B), seed=synth.SEED0 + 1000 * rank)
+    d_u = torch.from_numpy(uniq).to(dev)
+    reps = (B + d_u.shape[0] - 1) // d_u.shape[0]
+    d_in = d_u.repeat(reps, 1, 1)[:B].contiguous()          # (B, H, W) u8, tight pitch 1920
+    d_out = torch.empty_like(d_in)
+    del d_u
+
+    ctx = api.Context(W, H, 1, B, api.MODE_R, device=local)
+    ctx.set_thresholds(LOW, HIGH)
+    ctx.set_tuning(a.chunk, a.hyst_launches)
+    stream = torch.cuda.current_stream(dev)
+    ctx.set_stream(stream.cuda_stream)
+
+    def step():
+        ctx.run_device(d_in.data_ptr(), W, W * H, d_out.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
+
+    for _ in range(a.warmup):
+        step()
+    ctx.sync()
+    torch.cuda.synchronize(dev)
+    ctx.enable_profiling(True)     # hipEvent pairs around the fused kernel, on the launch stream
+    ctx.profile_get(reset=True)
+
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    ctx.sync()                      # also verifies hysteresis convergence of the last step
+    sums, nruns = ctx.profile_get(reset=True)
+    work_launches, continued = ctx.hysteresis_info()
+
+    elapsed = t1 - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        frames_total = B * a.steps * world
+        fps = frames_total / elapsed
+        alg_bytes_per_launch = 2.0 * W * H * B                      # 2*W*H per mono frame
+        front_ms = sums[1] / max(nruns, 1)
+        hyst_ms = sums[2] / max(nruns, 1)
+        achieved = alg_bytes_per_launch / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
+        out = {
+            "metric": "frames/sec, 1080p grayscale Canny (5-stage, Mode R, device-resident)",
+            "value": round(fps, 1),
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
+            "ms_per_frame": round(elapsed / (a.steps * B) * 1e3, 6),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": f"synthetic ({a.kind}, {min(a.unique, B)} distinct frames tiled to the batch)",
+            "config": {"workload": f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU",
+                       "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}"},
+            "e2e_alg_GBps": round(2.0 * W * H * frames_total / elapsed / 1e9, 1),
+            "roofline": {
+                "bound": "hbm", "kernel": "k_front", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(achieved / HBM_MEASURED_COPY_GBPS, 4),
+                "traffic": None, "kernel_ms": round(front_ms, 4), "hyst_expand_ms": round(hyst_ms, 4), "launches_timed": nruns,
+            },
+            "hysteresis": {"launches_with_work": work_launches, "continued": continued},
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, d_in, d_out)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, d_in, d_out):
+    """The oracle (a CPU port of the reference pipeline, kind "port") timed on the host cores on a
+    bounded sample of the same frames; the GPU output for that sample is checked against it."""
+    from oracle import oracle as O   # test infrastructure: only this leg may touch it
+    O.build()
+    cores = os.cpu_count() or 1
+    n = a.cpu_frames or max(cores * 4, 16)
+    n = min(n, d_in.shape[0])
+    sample = d_in[:n].cpu().numpy()
+    O.canny_r_batch(sample[:min(n, cores)], LOW, HIGH, threads=cores)   # warm the pages/threads
+    t0 = time.perf_counter()
+    ref = O.canny_r_batch(sample, LOW, HIGH, threads=cores)
+    dt = time.perf_counter() - t0
+    same = bool(np.array_equal(ref, d_out[:n].cpu().numpy()))
+    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} of the benchmark's 1080p frames, OpenMP over frames, oracle/canny_oracle.c",
+            "gpu_output_matches": same}
+
+
+if __name__ == "__main__":
+    main()

@@ -39,12 +39,13 @@ CANNY_STAGES = {
 }
 
 MODE_R, MODE_O = 0, 1
+OPT_NMS_SATURATE = 1
 
 # every symbol include/hipcanny.h declares
 ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
-    "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms",
-    "hc_device_ptrs", "hc_last_hysteresis_info", "hc_set_tuning", "hc_selftest", "hc_last_error", "hc_version",
+    "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
+    "hc_device_ptrs", "hc_last_hysteresis_info", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
 ]
 
 _lib = None
@@ -54,11 +55,28 @@ class HipCannyError(RuntimeError):
     pass
 
 
+def preload_hip_runtime():
+    """One HIP runtime per process.  The PyTorch wheel bundles its own libamdhip64 (file name
+    libamdhip64.so, SONAME libamdhip64.so.7 -- the same SONAME as /opt/rocm's).  If libhipcanny
+    pulled in /opt/rocm's copy first, a later `import torch` would load the bundled one as well and
+    the second runtime finds no GPU.  Loading torch's copy first (without importing torch) makes
+    every later user -- this library, torch, oracle/_ref -- resolve to that single instance."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return None
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        return C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    return None
+
+
 def load_library():
     """Loads libhipcanny.so (fails loudly when it has not been built)."""
     global _lib
     if _lib is not None:
         return _lib
+    preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise HipCannyError(f"{LIB_PATH} is missing: run `python -m cudacam_amd.build` (hipcc, gfx950). There is no CPU fallback.")
     L = C.CDLL(LIB_PATH)
@@ -78,9 +96,11 @@ def load_library():
     L.hc_set_stream.argtypes = [vp, vp]
     L.hc_enable_profiling.argtypes = [vp, i]
     L.hc_stage_time_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
+    L.hc_profile_get.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), i]
     L.hc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.hc_last_hysteresis_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.hc_set_tuning.argtypes = [vp, i, i]
+    L.hc_set_option.argtypes = [vp, i, i]
     L.hc_selftest.argtypes = [i]
     L.hc_last_error.restype = C.c_char_p
     L.hc_version.restype = C.c_char_p
@@ -133,6 +153,9 @@ class Context:
     def set_tuning(self, chunk_rows=0, hyst_launches=4):
         _ck(self.lib.hc_set_tuning(self.handle, int(chunk_rows), int(hyst_launches)))
 
+    def set_option(self, option, value):
+        _ck(self.lib.hc_set_option(self.handle, int(option), int(value)))
+
     def set_stream(self, stream_handle):
         _ck(self.lib.hc_set_stream(self.handle, C.c_void_p(stream_handle)))
 
@@ -143,6 +166,13 @@ class Context:
         ms = C.c_float()
         _ck(self.lib.hc_stage_time_ms(self.handle, int(stage), C.byref(ms)))
         return ms.value
+
+    def profile_get(self, reset=True):
+        """(sum_ms[3], nruns) over all profiled runs since the last reset: stage 0 / front / hysteresis+expand."""
+        sums = (C.c_double * 3)()
+        n = C.c_long()
+        _ck(self.lib.hc_profile_get(self.handle, sums, C.byref(n), int(bool(reset))))
+        return [sums[0], sums[1], sums[2]], n.value
 
     def upload(self, frames):
         """frames: (n,H,W) / (n,H,W,3) uint8, or a single frame."""

@@ -35,6 +35,7 @@ struct FrontParams {
   int total_items;         // nframes * nstrips * nchunks
   // thresholds on S = sumX^2 + sumY^2 for "u8-wrapped gradient > T" (band test)
   u32 a_lo[3], a_hi[3];
+  u32 wrap_limit;  // S >= wrap_limit: gradient >= 256, the wrap bands apply (0xFFFFFFFF: saturating variant)
 };
 
 struct HystParams {
@@ -74,7 +75,7 @@ hipError_t launch_gray(const uint8_t *bgr, size_t bpitch, size_t bfs, uint8_t *m
 hipError_t launch_gauss(const uint8_t *mono, size_t mpitch, size_t mfs, uint8_t *blur, size_t bpitch, size_t bfs, int W, int H, int n, hipStream_t s);
 hipError_t launch_sobel(const uint8_t *blur, size_t bpitch, size_t bfs, int16_t *sx, int16_t *sy, size_t spitch_elems, size_t sfs_elems, int W, int H, int n, hipStream_t s);
 hipError_t launch_graddisp(const int16_t *sx, const int16_t *sy, size_t spitch_elems, size_t sfs_elems, uint8_t *out, size_t opitch, size_t ofs, int W, int H, int n, hipStream_t s);
-hipError_t launch_nms(const int16_t *sx, const int16_t *sy, size_t spitch_elems, size_t sfs_elems, uint8_t *out, size_t opitch, size_t ofs, int W, int H, int n, hipStream_t s);
+hipError_t launch_nms(const int16_t *sx, const int16_t *sy, size_t spitch_elems, size_t sfs_elems, uint8_t *out, size_t opitch, size_t ofs, int W, int H, int n, int saturate, hipStream_t s);
 hipError_t launch_thresh(const uint8_t *nms, size_t npitch, size_t nfs, uint8_t *out, size_t opitch, size_t ofs, int W, int H, int n, int low, int high, hipStream_t s);
 
 }  // namespace hc

@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
     if (c >= r0 && c < H) {  // wave-uniform (c < r0 + CHUNK by the loop bound)
       u64 strong[4], cand[4];
       const u32 mx = max(max(Sc[1], Sc[2]), max(Sc[3], Sc[4]));
-      const bool wrap = __ballot(mx >= 262144u) != 0;  // some gradient >= 256: u8 wrap bands needed
+      const bool wrap = __ballot(mx >= p.wrap_limit) != 0;  // some gradient >= 256: u8 wrap bands needed
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const u32 g = Sc[1 + q];
@@ -605,7 +605,7 @@ __global__ void k_graddisp(const int16_t *sx, const int16_t *sy, size_t sp, size
   out[f * ofs + row * op + col] = (uint8_t)min(g, 255u);
 }
 
-__global__ void k_nms(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H)
+__global__ void k_nms(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int saturate)
 {
   PIX_PROLOG
   const int16_t *X = sx + f * sfs, *Y = sy + f * sfs;
@@ -627,7 +627,8 @@ __global__ void k_nms(const int16_t *sx, const int16_t *sy, size_t sp, size_t sf
   else if (bin == 2) { q = S(row, col + 1); r = S(row, col - 1); }
   else { q = S(row - 1, col - 1); r = S(row + 1, col + 1); }
   const bool keep = q <= g && r <= g;
-  out[f * ofs + row * op + col] = keep ? (uint8_t)(isqrt_u32((u32)g >> 2) & 0xFFu) : 0;
+  const u32 gt = isqrt_u32((u32)g >> 2);
+  out[f * ofs + row * op + col] = keep ? (uint8_t)(saturate ? min(gt, 255u) : (gt & 0xFFu)) : 0;
 }
 
 __global__ void k_thresh(const uint8_t *nms, size_t np, size_t nfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int low, int high)
@@ -646,8 +647,8 @@ hipError_t launch_sobel(const uint8_t *blur, size_t bpitch, size_t bfs, int16_t 
 { PIX_GRID; hipLaunchKernelGGL(k_sobel, grd, blk, 0, s, blur, bpitch, bfs, sx, sy, sp, sfs, W, H); return hipGetLastError(); }
 hipError_t launch_graddisp(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int n, hipStream_t s)
 { PIX_GRID; hipLaunchKernelGGL(k_graddisp, grd, blk, 0, s, sx, sy, sp, sfs, out, op, ofs, W, H); return hipGetLastError(); }
-hipError_t launch_nms(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int n, hipStream_t s)
-{ PIX_GRID; hipLaunchKernelGGL(k_nms, grd, blk, 0, s, sx, sy, sp, sfs, out, op, ofs, W, H); return hipGetLastError(); }
+hipError_t launch_nms(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int n, int saturate, hipStream_t s)
+{ PIX_GRID; hipLaunchKernelGGL(k_nms, grd, blk, 0, s, sx, sy, sp, sfs, out, op, ofs, W, H, saturate); return hipGetLastError(); }
 hipError_t launch_thresh(const uint8_t *nms, size_t np, size_t nfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int n, int low, int high, hipStream_t s)
 { PIX_GRID; hipLaunchKernelGGL(k_thresh, grd, blk, 0, s, nms, np, nfs, out, op, ofs, W, H, low, high); return hipGetLastError(); }
 

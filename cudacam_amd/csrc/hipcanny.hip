@@ -33,6 +33,7 @@ constexpr int MAX_HYST_LAUNCHES = 16;
 struct hc_ctx {
   int device = 0, W = 0, H = 0, C = 1, max_batch = 1, mode = HC_MODE_R;
   int low = 10, high = 40;
+  int nms_saturate = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;
   // internal pitched frames
   uint8_t *d_in = nullptr, *d_mono = nullptr, *d_out = nullptr;
@@ -54,9 +55,14 @@ struct hc_ctx {
   int last_work_launches = 0, last_continued = 0;
   int uploaded = 0, last_run_n = 0;
   bool profiling = false;
-  hipEvent_t ev[4] = { nullptr, nullptr, nullptr, nullptr };
+  // hipEvent ring: 4 events per run (start, after stage 0, after the fused/stage kernels, end)
+  static constexpr int EV_RUNS = 256;
+  std::vector<hipEvent_t> evpool;
+  int ev_head = 0, ev_count = 0;   // runs recorded since the last collect
+  hipEvent_t *ev = nullptr;        // the 4 events of the run being recorded
   float stage_ms[6] = { 0, 0, 0, 0, 0, 0 };
-  bool ev_valid = false;
+  double prof_sum[3] = { 0, 0, 0 };
+  long prof_runs = 0;
 };
 
 namespace {
@@ -82,12 +88,16 @@ int ensure_stage_scratch(hc_ctx *c)
 
 bool aligned4(const void *p, size_t a, size_t b) { return (((uintptr_t)p | a | b) & 3u) == 0; }
 
-void band_thresholds(int T, u32 a[3])
+// "stored u8 gradient > T" as thresholds on S = sumX^2+sumY^2 (gradient g = isqrt(S>>2)):
+// wrapping variant: g in [256k+T+1, 256k+255] for k = 0,1,2  ->  S >= a[k] (and below 4*(256(k+1))^2);
+// saturating variant: min(g,255) > T  ->  S >= a[0], never for T = 255.
+void band_thresholds(int T, bool saturate, u32 a[3])
 {
   for (int k = 0; k < 3; ++k) {
     const u64 g = 256ull * k + (u64)T + 1;
     a[k] = (u32)std::min<u64>(4ull * g * g, 0xFFFFFFFFull);
   }
+  if (saturate && T >= 255) a[0] = 0xFFFFFFFFu;
 }
 
 int pick_chunk(const hc_ctx *c, int nframes)
@@ -181,7 +191,11 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   if (out_internal) { dst = c->d_out; dp = c->out_pitch; dfs = c->out_fs; }
   c->pend_copy_dst = nullptr;
 
-  if (c->profiling) HIPCK(hipEventRecord(c->ev[0], c->stream));
+  const bool prof = c->profiling && c->ev_count < hc_ctx::EV_RUNS;  // ring full: this run goes untimed
+  if (prof) {
+    c->ev = &c->evpool[(size_t)((c->ev_head + c->ev_count) % hc_ctx::EV_RUNS) * 4];
+    HIPCK(hipEventRecord(c->ev[0], c->stream));
+  }
   // stage 0 (cannyEdgeH.cu:214-227); 1-channel input skips it (the reference's mono path is broken, SURVEY §3 ii)
   const uint8_t *mono = src;
   size_t mp = sp, mfs = sfs;
@@ -195,7 +209,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   } else if (stage == HC_STAGE_MONO) {
     if (int rc = copy_frames_d2d(c, dst, dp, dfs, src, sp, sfs, (size_t)W, n)) return rc;
   }
-  if (c->profiling) HIPCK(hipEventRecord(c->ev[1], c->stream));
+  if (stage == HC_STAGE_HYSTER) HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * MAX_HYST_LAUNCHES, c->stream));
+  if (prof) HIPCK(hipEventRecord(c->ev[1], c->stream));
 
   if (stage == HC_STAGE_HYSTER) {
     FrontParams fp{};
@@ -203,11 +218,11 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     const int chunk = pick_chunk(c, n);
     fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n;
     fp.total_items = n * fp.nstrips * fp.nchunks;
-    band_thresholds(c->low, fp.a_lo);
-    band_thresholds(c->high, fp.a_hi);
-    HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * MAX_HYST_LAUNCHES, c->stream));
+    band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);
+    band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
+    fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
     HIPCK(launch_front(fp, chunk, c->stream));
-    if (c->profiling) HIPCK(hipEventRecord(c->ev[2], c->stream));
+    if (prof) HIPCK(hipEventRecord(c->ev[2], c->stream));
     if (int rc = run_hyst_expand(c, dst, dp, dfs, n)) return rc;
   } else if (stage > HC_STAGE_MONO) {
     if (int rc = ensure_stage_scratch(c)) return rc;
@@ -221,13 +236,13 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       else {
         uint8_t *nms = stage == HC_STAGE_NMS ? dst : c->d_nms;
         const size_t np = stage == HC_STAGE_NMS ? dp : bp, nfs = stage == HC_STAGE_NMS ? dfs : bfs;
-        HIPCK(launch_nms(c->d_sx, c->d_sy, bp, bfs, nms, np, nfs, W, H, n, c->stream));
+        HIPCK(launch_nms(c->d_sx, c->d_sy, bp, bfs, nms, np, nfs, W, H, n, c->nms_saturate, c->stream));
         if (stage == HC_STAGE_THRESH) HIPCK(launch_thresh(nms, np, nfs, dst, dp, dfs, W, H, n, c->low, c->high, c->stream));
       }
     }
-    if (c->profiling) HIPCK(hipEventRecord(c->ev[2], c->stream));
-  } else if (c->profiling) HIPCK(hipEventRecord(c->ev[2], c->stream));
-  if (c->profiling) { HIPCK(hipEventRecord(c->ev[3], c->stream)); c->ev_valid = true; }
+    if (prof) HIPCK(hipEventRecord(c->ev[2], c->stream));
+  } else if (prof) HIPCK(hipEventRecord(c->ev[2], c->stream));
+  if (prof) { HIPCK(hipEventRecord(c->ev[3], c->stream)); c->ev_count++; }
 
   if (out_internal) {
     if (int rc = copy_frames_d2d(c, out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)W, n)) return rc;
@@ -277,7 +292,8 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   good = good && ok(hipMalloc((void **)&c->d_bm, sizeof(u64) * BM_WORDS * (size_t)height * c->nstrips * max_batch), "hipMalloc(bit planes)");
   good = good && ok(hipMalloc((void **)&c->d_flags, sizeof(u32) * MAX_HYST_LAUNCHES), "hipMalloc(flags)");
   good = good && ok(hipHostMalloc((void **)&c->h_flags, sizeof(u32) * MAX_HYST_LAUNCHES, hipHostMallocDefault), "hipHostMalloc(flags)");
-  for (int i = 0; good && i < 4; ++i) good = ok(hipEventCreate(&c->ev[i]), "hipEventCreate");
+  c->evpool.assign((size_t)hc_ctx::EV_RUNS * 4, nullptr);
+  for (size_t i = 0; good && i < c->evpool.size(); ++i) good = ok(hipEventCreate(&c->evpool[i]), "hipEventCreate");
   if (good) {
     // cannyEdgeH.cu:372-380: float coefficients K * (1 / 159.0f), computed in binary32 on the host
     float gk[25];
@@ -297,7 +313,7 @@ void hc_destroy(hc_ctx *c)
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
   for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_bm, (void *)c->d_flags }) (void)hipFree(q);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
-  for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+  for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -335,6 +351,15 @@ int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
   if (hyst_launches < 1 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range");
   if (int rc = finish_pending(c)) return rc;
   c->chunk = chunk_rows; c->hyst_launches = hyst_launches;
+  return HC_OK;
+}
+
+int hc_set_option(hc_ctx *c, int option, int value)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (option != HC_OPT_NMS_SATURATE) return fail(HC_E_ARG, "hc_set_option: unknown option");
+  if (int rc = finish_pending(c)) return rc;
+  c->nms_saturate = value != 0;
   return HC_OK;
 }
 
@@ -400,16 +425,20 @@ int hc_sync(hc_ctx *c)
   HIPCK(hipSetDevice(c->device));
   if (int rc = finish_pending(c)) return rc;
   HIPCK(hipStreamSynchronize(c->stream));
-  if (c->profiling && c->ev_valid) {
+  while (c->ev_count > 0) {  // collect the event pairs of every run recorded since the last sync
+    hipEvent_t *e = &c->evpool[(size_t)c->ev_head * 4];
     float a = 0, b = 0, d = 0;
-    HIPCK(hipEventElapsedTime(&a, c->ev[0], c->ev[1]));
-    HIPCK(hipEventElapsedTime(&b, c->ev[1], c->ev[2]));
-    HIPCK(hipEventElapsedTime(&d, c->ev[2], c->ev[3]));
+    HIPCK(hipEventElapsedTime(&a, e[0], e[1]));
+    HIPCK(hipEventElapsedTime(&b, e[1], e[2]));
+    HIPCK(hipEventElapsedTime(&d, e[2], e[3]));
     for (float &m : c->stage_ms) m = 0;
     c->stage_ms[HC_STAGE_MONO] = a;
     c->stage_ms[HC_STAGE_THRESH] = b;
     c->stage_ms[HC_STAGE_HYSTER] = d;
-    c->ev_valid = false;
+    c->prof_sum[0] += a; c->prof_sum[1] += b; c->prof_sum[2] += d;
+    c->prof_runs++;
+    c->ev_head = (c->ev_head + 1) % hc_ctx::EV_RUNS;
+    c->ev_count--;
   }
   return HC_OK;
 }
@@ -430,6 +459,16 @@ int hc_enable_profiling(hc_ctx *c, int on)
 {
   if (!c) return fail(HC_E_ARG, "null context");
   c->profiling = on != 0;
+  return HC_OK;
+}
+
+int hc_profile_get(hc_ctx *c, double sum_ms[3], long *nruns, int reset)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (int rc = hc_sync(c)) return rc;
+  if (sum_ms) for (int i = 0; i < 3; ++i) sum_ms[i] = c->prof_sum[i];
+  if (nruns) *nruns = c->prof_runs;
+  if (reset) { c->prof_sum[0] = c->prof_sum[1] = c->prof_sum[2] = 0; c->prof_runs = 0; }
   return HC_OK;
 }
 

@@ -91,6 +91,10 @@ int hc_set_stream(hc_ctx *ctx, void *hip_stream);
  * HC_STAGE_THRESH, hysteresis under HC_STAGE_HYSTER).  Off by default on the batch path. */
 int hc_enable_profiling(hc_ctx *ctx, int on);
 int hc_stage_time_ms(hc_ctx *ctx, int stage, float *ms);
+/* Sums over every profiled run since the last reset (up to 256 runs may be in flight between
+ * syncs): sum_ms[0] stage 0, [1] fused front kernel (or the tap kernels), [2] hysteresis + expand.
+ * This is the accumulating counterpart of timerManager::addTime (src/utils/timer.hpp:27-39). */
+int hc_profile_get(hc_ctx *ctx, double sum_ms[3], long *nruns, int reset);
 
 /* Internal device buffers (input frames, output images) and their pitch / frame stride. */
 int hc_device_ptrs(hc_ctx *ctx, void **d_in, void **d_out, size_t *in_pitch, size_t *out_pitch, size_t *in_frame_stride,
@@ -101,6 +105,13 @@ int hc_last_hysteresis_info(hc_ctx *ctx, int *launches_with_work, int *continued
 
 /* Tuning knobs (rows per fused work item: 0 = auto; hysteresis launches queued per run). */
 int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
+
+/* Options.  HC_OPT_NMS_SATURATE (default 0): the reference stores `min((unsigned char)gradVal, 255)`
+ * (src/cvp/cannyEdgeD.cu:267), an out-of-range float->u8 cast for gradients 256..721.  0 = the
+ * canonical Mode R reading: the value wraps mod 256 (integer min folds away, low byte stored).
+ * 1 = min(g, 255): what the same source line yields when compiled by hipcc for gfx950. */
+enum { HC_OPT_NMS_SATURATE = 1 };
+int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* Device self-test of the cross-lane / packed-math primitives the kernels rely on. 0 = ok. */
 int hc_selftest(int device);

@@ -183,7 +183,7 @@ int orc_dir_bin_float(int sumx, int sumy)
 }
 
 /* ---- stage 3: src/cvp/cannyEdgeD.cu:201-270 -------------------------------------------------- */
-void orc_nms(const int16_t *sumx, const int16_t *sumy, size_t sstride, int w, int h, uint8_t *nms, size_t nstride)
+void orc_nms(const int16_t *sumx, const int16_t *sumy, size_t sstride, int w, int h, uint8_t *nms, size_t nstride, int saturate)
 {
   /* Comparisons of the float grad are comparisons of the integer S = sumx^2+sumy^2 (grad is a
    * strictly increasing function of S; checked exhaustively in tests). */
@@ -200,8 +200,14 @@ void orc_nms(const int16_t *sumx, const int16_t *sumy, size_t sstride, int w, in
       long q = SQ(r + dq[bin][0], c + dq[bin][1]);
       long rr = SQ(r + dr[bin][0], c + dr[bin][1]);
       int keep = (q <= g) && (rr <= g);
-      /* :267 `min((unsigned char)gradVal, 255)`: cast first -> wraps mod 256 (App. A.5) */
-      nms[(size_t)r * nstride + c] = keep ? (uint8_t)(orc_grad_trunc_int(sx, sy) & 0xFF) : 0;
+      /* :267 `min((unsigned char)gradVal, 255)`: the cast comes first and is out of range (UB) for
+       * gradients 256..721.  Canonical Mode R (saturate == 0): wrap mod 256 -- integer min(int,int)
+       * folds away and the low byte is stored (nvcc by analysis, x86 host emulation observed, SURVEY
+       * App. A.5/C.4).  saturate != 0: min(g, 255) -- what hipcc makes of the same line on gfx950
+       * (HIP resolves min(unsigned char,int) to the double overload and skips the byte truncation;
+       * observed with oracle/_ref). */
+      int gt = orc_grad_trunc_int(sx, sy);
+      nms[(size_t)r * nstride + c] = keep ? (uint8_t)(saturate ? (gt > 255 ? 255 : gt) : (gt & 0xFF)) : 0;
     }
 #undef SQ
 }
@@ -330,7 +336,7 @@ void orc_grad_display(const int16_t *sumx, const int16_t *sumy, size_t sstride, 
     }
 }
 
-int orc_canny_r(const uint8_t *in, size_t stride, int w, int h, int channels, int low, int high, orc_outputs *o)
+int orc_canny_r(const uint8_t *in, size_t stride, int w, int h, int channels, int low, int high, int saturate, orc_outputs *o)
 {
   if (w <= 0 || h <= 0 || (channels != 1 && channels != 3)) return -1;
   size_t n = (size_t)w * h;
@@ -341,7 +347,7 @@ int orc_canny_r(const uint8_t *in, size_t stride, int w, int h, int channels, in
   else for (int r = 0; r < h; ++r) memcpy(mono + (size_t)r * w, in + (size_t)r * stride, (size_t)w); /* stage 0 skipped */
   orc_gaussian_shortcut(mono, (size_t)w, w, h, blur, (size_t)w); /* == orc_gaussian(fused=1), tested */
   orc_sobel(blur, (size_t)w, w, h, sx, sy, (size_t)w);
-  orc_nms(sx, sy, (size_t)w, w, h, nms, (size_t)w);
+  orc_nms(sx, sy, (size_t)w, w, h, nms, (size_t)w, saturate);
   orc_threshold(nms, (size_t)w, w, h, low, high, thr, (size_t)w);
   orc_hysteresis(thr, (size_t)w, w, h, edges, (size_t)w);
   if (o) {
@@ -372,7 +378,7 @@ int orc_canny_r_batch(const uint8_t *in, int w, int h, int nframes, int low, int
     orc_outputs o;
     memset(&o, 0, sizeof o);
     o.edges = edges + n * (size_t)f;
-    if (orc_canny_r(in + n * (size_t)f, (size_t)w, w, h, 1, low, high, &o)) rc = -1;
+    if (orc_canny_r(in + n * (size_t)f, (size_t)w, w, h, 1, low, high, 0, &o)) rc = -1;
   }
   return rc;
 }

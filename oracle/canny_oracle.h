@@ -64,8 +64,9 @@ int orc_grad_trunc_int(int sumx, int sumy);
 /* The float gradient itself (for the GRADIENT display stage, float2uchar cannyEdgeD.cu:35-50). */
 float orc_grad_float(int sumx, int sumy);
 
-/* cannyEdgeD.cu:201-270: keep iff q <= g && r <= g along the bin; out = (u8)(int)g (wraps mod 256). */
-void orc_nms(const int16_t *sumx, const int16_t *sumy, size_t sstride, int w, int h, uint8_t *nms, size_t nstride);
+/* cannyEdgeD.cu:201-270: keep iff q <= g && r <= g along the bin; out = (u8)(int)g: wraps mod 256
+ * (canonical) or, with saturate != 0, min(g,255) (the hipcc lowering of the same line, see .c). */
+void orc_nms(const int16_t *sumx, const int16_t *sumy, size_t sstride, int w, int h, uint8_t *nms, size_t nstride, int saturate);
 
 /* cannyEdgeD.cu:273-293 */
 void orc_threshold(const uint8_t *nms, size_t nstride, int w, int h, int low, int high, uint8_t *thr, size_t tstride);
@@ -89,7 +90,7 @@ typedef struct {
   uint8_t *mono, *blur, *grad_disp, *nms, *thresh, *edges;
   int16_t *sumx, *sumy;
 } orc_outputs;
-int orc_canny_r(const uint8_t *in, size_t stride, int w, int h, int channels, int low, int high, orc_outputs *o);
+int orc_canny_r(const uint8_t *in, size_t stride, int w, int h, int channels, int low, int high, int saturate, orc_outputs *o);
 
 /* Batch helper for the CPU baseline: nframes tight mono frames -> edge maps, `threads` OpenMP threads. */
 int orc_canny_r_batch(const uint8_t *in, int w, int h, int nframes, int low, int high, uint8_t *edges, int threads);

@@ -97,12 +97,12 @@ def sobel(blur):
     return sx, sy
 
 
-def nms(sx, sy):
+def nms(sx, sy, saturate=False):
     sx = np.ascontiguousarray(sx, np.int16)
     sy = np.ascontiguousarray(sy, np.int16)
     h, w = sx.shape
     out = np.empty((h, w), np.uint8)
-    lib().orc_nms(_p16(sx), _p16(sy), C.c_size_t(w), w, h, _p8(out), C.c_size_t(w))
+    lib().orc_nms(_p16(sx), _p16(sy), C.c_size_t(w), w, h, _p8(out), C.c_size_t(w), int(bool(saturate)))
     return out
 
 
@@ -131,7 +131,7 @@ def hysteresis_tiled(thr, tile=30, max_extra=100):
     return out, n.value
 
 
-def canny_r(img, low=10, high=40, stages=False):
+def canny_r(img, low=10, high=40, stages=False, saturate=False):
     """Mode R pipeline.  img: (h,w) u8 mono or (h,w,3) u8 BGR.  Returns edges, or a dict of every
     stage output when stages=True."""
     img = _c8(img)
@@ -145,7 +145,7 @@ def canny_r(img, low=10, high=40, stages=False):
         setattr(o, k, _p8(res[k]))
     o.sumx = _p16(res["sumx"])
     o.sumy = _p16(res["sumy"])
-    rc = lib().orc_canny_r(_p8(img), C.c_size_t(w * ch), w, h, ch, int(low), int(high), C.byref(o))
+    rc = lib().orc_canny_r(_p8(img), C.c_size_t(w * ch), w, h, ch, int(low), int(high), int(bool(saturate)), C.byref(o))
     if rc:
         raise ValueError("orc_canny_r failed")
     return res if stages else res["edges"]

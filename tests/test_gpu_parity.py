@@ -87,6 +87,19 @@ def test_thresholds(oracle, low, high):
         _diff(ctx.process(img, api.CannyStage.HYSTER)[0], want["edges"], "edges")
 
 
+def test_saturate_option(oracle):
+    img = synth.steps(300, 200, 255, "diagonal")
+    img[20:120, 150:290] = synth.noise(140, 100, 5)
+    with api.Context(300, 200, 1, 1) as ctx:
+        ctx.set_option(api.OPT_NMS_SATURATE, 1)
+        for (lo, hi) in ((10, 40), (200, 255), (255, 255)):
+            ctx.set_thresholds(lo, hi)
+            want = oracle.canny_r(img, lo, hi, stages=True, saturate=True)
+            for stage in (api.CannyStage.NMS, api.CannyStage.THRESH, api.CannyStage.HYSTER):
+                _diff(ctx.process(img, stage)[0], want[STAGE_KEYS[stage]], f"saturate {lo}/{hi} {stage.name}")
+        assert (oracle.canny_r(img, 10, 40, saturate=True) != oracle.canny_r(img, 10, 40)).any()
+
+
 def test_batch_1080p(oracle):
     frames = np.stack([synth.natural(1920, 1080, 100 + i) for i in range(3)] + [synth.noise(1920, 1080, 200)])
     want = oracle.canny_r_batch(frames, 10, 40, threads=8)
