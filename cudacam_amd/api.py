@@ -45,7 +45,7 @@ OPT_NMS_SATURATE = 1
 ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
-    "hc_device_ptrs", "hc_last_hysteresis_info", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
+    "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
 ]
 
 _lib = None
@@ -99,6 +99,7 @@ def load_library():
     L.hc_profile_get.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), i]
     L.hc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.hc_last_hysteresis_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
+    L.hc_hysteresis_stats.argtypes = [vp, C.POINTER(C.c_uint), i]
     L.hc_set_tuning.argtypes = [vp, i, i]
     L.hc_set_option.argtypes = [vp, i, i]
     L.hc_selftest.argtypes = [i]
@@ -210,6 +211,12 @@ class Context:
         a, b = C.c_int(), C.c_int()
         _ck(self.lib.hc_last_hysteresis_info(self.handle, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def hysteresis_stats(self, launches=6):
+        """[(sweeps_sum, sweeps_max, active_tiles)] per queued hysteresis launch of the last run."""
+        buf = (C.c_uint * (3 * launches))()
+        _ck(self.lib.hc_hysteresis_stats(self.handle, buf, 3 * launches))
+        return [(buf[3 * k], buf[3 * k + 1], buf[3 * k + 2]) for k in range(launches)]
 
     def process(self, frames, final_stage=CannyStage.HYSTER):
         """upload -> run -> download convenience."""

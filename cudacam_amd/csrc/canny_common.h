@@ -19,17 +19,15 @@ constexpr int PX_PER_LANE = 4;
 constexpr int STRIP_W = (LANES - 2) * PX_PER_LANE;  // 248
 constexpr int STRIP_HALO = PX_PER_LANE;             // 4 columns = one lane
 
-// Bit-plane record of one (frame, strip, row): 8 x u64.  Word j (0..3): STRONG plane of pixel slot j
-// (bit l <-> column strip*STRIP_W - 4 + 4*l + j); word 4+j: CANDIDATE plane (includes strong).
-// Bits 0 and 63 (the halo lanes) are stored as 0.
-constexpr int BM_WORDS = 8;
-constexpr u64 BM_VALID = 0x7FFFFFFFFFFFFFFEull;
-
+// Bit planes: two plain bitmaps per frame, STRONG and CANDIDATE (candidate includes strong):
+// bit c of a row <-> column c, rows padded to RD dwords.  A strip's 248 valid columns are 31 whole
+// bytes, so each wave-row of k_front stores its 31 bytes at byte offset strip*31 of the row.
 struct FrontParams {
   const uint8_t *in;       // mono u8 frames, pitched
   size_t in_pitch;         // bytes per row   (multiple of 4)
   size_t in_frame_stride;  // bytes per frame (multiple of 4)
-  u64 *bm;                 // bit planes [frame][strip][H][8]
+  u32 *sbits, *cbits;      // bit planes [frame][H][RD]
+  int RD;                  // dwords per bit-plane row
   int W, H;
   int nstrips, nchunks, nframes;
   int total_items;         // nframes * nstrips * nchunks
@@ -39,26 +37,32 @@ struct FrontParams {
 };
 
 struct HystParams {
-  u64 *bm;
-  int H, nstrips, nframes;
-  int tile_rows;   // rows per workgroup = 64 * waves
-  int nrtiles;     // ceil(H / tile_rows)
-  u32 *flags;      // flags[k] != 0: launch k changed something another tile can see
+  u32 *sbits;
+  const u32 *cbits;
+  int RD, H, nframes;
+  int tile_rows;   // rows per wave
+  int waves;       // waves per workgroup; a workgroup tile is waves * tile_rows rows
+  int nrtiles;     // workgroup tiles per frame = ceil(H / (waves * tile_rows))
+  u32 *flags;      // flags[k] != 0: launch k changed a tile-boundary row (another launch is needed)
+  uint8_t *tflags; // [2][nframes][nrtiles]: bit0 first row changed, bit1 last row changed (per launch parity)
   int iter;        // index of this launch
+  u32 *stats;      // optional diagnostics (3 words per launch) or null
+  int first_pass;  // the planes come straight from k_front / k_pack: rows are not yet closed under the in-row fill
 };
 
 struct ExpandParams {
-  const u64 *bm;
+  const u32 *sbits;
+  int RD;
   uint8_t *out;
   size_t out_pitch, out_frame_stride;
-  int W, H, nstrips, nframes;
+  int W, H, nframes;
 };
 
 struct PackParams {  // tri-state u8 map (0/128/255) -> bit planes
   const uint8_t *in;
   size_t in_pitch, in_frame_stride;
-  u64 *bm;
-  int W, H, nstrips, nframes;
+  u32 *sbits, *cbits;
+  int RD, W, H, nframes;
 };
 
 // ---- host-callable launchers (defined in canny_kernels.hip) -----------------------------------
@@ -69,6 +73,7 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 hipError_t launch_expand(const ExpandParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
 size_t front_lds_bytes(int chunk_rows);
+size_t hyst_lds_bytes(int RD, int block_rows);
 
 // plain per-stage kernels (exact, unfused): the `finalStage` taps MONO..THRESH of CannyEdge::run
 hipError_t launch_gray(const uint8_t *bgr, size_t bpitch, size_t bfs, uint8_t *mono, size_t mpitch, size_t mfs, int W, int H, int n, hipStream_t s);

@@ -13,6 +13,7 @@
 // float Gaussian chain (via the exact shortcut explained at gauss_row), the u8 wrap of gradients
 // >= 256 and the non-strict NMS.
 #include "canny_common.h"
+#include <cstdio>
 
 namespace hc {
 
@@ -152,6 +153,15 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
     vm[k] = in ? 0xFFFFFFFFu : 0u;
     cmask |= in ? (0xFFu << (8 * k)) : 0u;
   }
+  // packed-u16 "invalid pixel" masks: OR-ed into the division remainders so that pixels outside
+  // the image never look undecidable
+  const u32 inv0 = (vm[0] ? 0u : 0xFFFFu) | (vm[1] ? 0u : 0xFFFF0000u);
+  const u32 inv1 = (vm[2] ? 0u : 0xFFFFu) | (vm[3] ? 0u : 0xFFFF0000u);
+  // packed-i16 masks (0xFFFF per in-image pixel) for the Sobel pairs, kept as plain VGPR values
+  const u32 pm0 = __builtin_amdgcn_perm(0u, cmask, 0x01010000u), pm1 = __builtin_amdgcn_perm(0u, cmask, 0x03030202u);
+  // nibble of pixel slots this lane may set in the bit planes (lanes 1..62, columns inside the image)
+  const u32 oknib1 = (lane >= 1 && lane <= 62) ? ((cmask & 1u) | ((cmask >> 7) & 2u) | ((cmask >> 14) & 4u) | ((cmask >> 21) & 8u)) : 0u;
+  const u32 oknib = oknib1 | (oknib1 << 8);
   const bool col_any = cmask != 0;
   const uint8_t *frame_base = p.in + (size_t)frame * p.in_frame_stride;
   const uint8_t *src = frame_base + c0;  // dereferenced only where col_any
@@ -171,29 +181,13 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   auto load_row = [&](int row) -> u32 {
     u32 v = 0;
     if (row >= 0 && row < H && col_any) v = *reinterpret_cast<const u32 *>(src + (size_t)row * p.in_pitch);
-    return v & cmask;
+    return v;
   };
 
-  auto fixup = [&]() {
-    wave_lds_sync();
-    for (int base = 0; base < qn; base += 64) {
-      const int e = base + lane;
-      if (e < qn) {
-        const u32 a = queue[e];
-        const int row = r0 - 2 + (int)(a >> 8);
-        const int col = strip * STRIP_W - STRIP_HALO + (int)(a & 255u);
-        blur_s[a] = (unsigned char)gauss_chain_px(frame_base, p.in_pitch, W, H, row, col);
-      }
-    }
-    wave_lds_sync();
-    qn = 0;
-  };
+  bool overflow = false;  // wave-uniform: more undecidable pixels than the queue holds (flat regions)
 
-  u32 xn1 = load_row(r0 - 4), xn2 = load_row(r0 - 3);
-  for (int jr = r0 - 4; jr < r0 + CHUNK + 4; ++jr) {
-    const u32 x = xn1;
-    xn1 = xn2;
-    xn2 = load_row(jr + 2);
+  auto phase1_row = [&](int jr, u32 xraw) {
+    const u32 x = xraw & cmask;
     const u32 A = unpack_lo(x), B = unpack_hi(x);
     const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
     const u32 m1 = pair_shift(A, Bl);  // (x-1, x0)
@@ -230,128 +224,188 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
         const u32 n3 = __builtin_amdgcn_udot2(U(Sp[1]), mhi, 0u, false) >> 23;
         const u32 B0 = n0 | (n1 << 16), B1 = n2 | (n3 << 16);
         const u16x2 c159 = { 159, 159 };
-        const u16x2 rem0 = U(Sp[0]) - U(B0) * c159, rem1 = U(Sp[1]) - U(B1) * c159;
+        const u32 rem0 = R(U(Sp[0]) - U(B0) * c159) | inv0, rem1 = R(U(Sp[1]) - U(B1) * c159) | inv1;
         bl = __builtin_amdgcn_perm(B1, B0, 0x06040200u) & cmask;
-        // queue the undecidable pixels (remainder 0, inside the image)
-        const bool f0 = rem0.x == 0 && vm[0], f1 = rem0.y == 0 && vm[1], f2 = rem1.x == 0 && vm[2], f3 = rem1.y == 0 && vm[3];
-        const u64 m0 = __ballot(f0), mm1 = __ballot(f1), m2 = __ballot(f2), m3 = __ballot(f3);
-        if (m0 | mm1 | m2 | m3) {
-          if (qn + 256 > QCAP) {
-            // flush: earlier rows of the slab are final, the current row is not written yet
-            fixup();
-          }
+        // undecidable pixels: remainder 0.  One cheap wave-wide test first.
+        const u16x2 z = __builtin_elementwise_min(U(rem0), U(rem1));
+        if (__ballot(z.x == 0 || z.y == 0) != 0) {
+          if (qn + 256 > QCAP) overflow = true;
+        }
+        if (!overflow && __ballot(z.x == 0 || z.y == 0) != 0) {
           const u32 abase = (u32)slot * 256u + (u32)lane * 4u;
-          if (m0) { if (f0) queue[qn + mbcnt64(m0)] = (unsigned short)(abase + 0); qn += __builtin_popcountll(m0); }
-          if (mm1) { if (f1) queue[qn + mbcnt64(mm1)] = (unsigned short)(abase + 1); qn += __builtin_popcountll(mm1); }
-          if (m2) { if (f2) queue[qn + mbcnt64(m2)] = (unsigned short)(abase + 2); qn += __builtin_popcountll(m2); }
-          if (m3) { if (f3) queue[qn + mbcnt64(m3)] = (unsigned short)(abase + 3); qn += __builtin_popcountll(m3); }
+          const bool f[4] = { (rem0 & 0xFFFFu) == 0, (rem0 >> 16) == 0, (rem1 & 0xFFFFu) == 0, (rem1 >> 16) == 0 };
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const u64 m = __ballot(f[k]);
+            if (f[k]) queue[qn + mbcnt64(m)] = (unsigned short)(abase + k);
+            qn += __builtin_popcountll(m);
+          }
         }
       }
       reinterpret_cast<u32 *>(blur_s)[slot * 64 + lane] = bl;
     }
+  };
+
+  {
+    constexpr int G = 4;  // rows per prefetch group (CHUNK + 8 is a multiple of 4)
+    u32 xn[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) xn[j] = load_row(r0 - 4 + j);
+#pragma nounroll
+    for (int jr0 = r0 - 4; jr0 < r0 + CHUNK + 4; jr0 += G) {
+      u32 xc[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) xc[j] = xn[j];
+      if (jr0 + G < r0 + CHUNK + 4)
+#pragma unroll
+        for (int j = 0; j < G; ++j) xn[j] = load_row(jr0 + G + j);
+#pragma unroll
+      for (int j = 0; j < G; ++j) phase1_row(jr0 + j, xc[j]);
+    }
   }
-  fixup();
+  // fix-up: the queued pixels get the literal chain.  If the queue overflowed (large flat regions:
+  // every pixel of a constant area has S = 159*v), every pixel of the slab is recomputed instead.
+  wave_lds_sync();
+  if (!overflow) {
+#pragma nounroll
+    for (int base = 0; base < qn; base += 64) {
+      const int e = base + lane;
+      if (e < qn) {
+        const u32 a = queue[e];
+        const int row = r0 - 2 + (int)(a >> 8);
+        const int col = strip * STRIP_W - STRIP_HALO + (int)(a & 255u);
+        blur_s[a] = (unsigned char)gauss_chain_px(frame_base, p.in_pitch, W, H, row, col);
+      }
+    }
+  } else {
+#pragma nounroll
+    for (int e = lane; e < FrontLds<CHUNK>::BROWS * 256; e += 64) {  // e = slot*256 + lane'*4 + k
+      const int row = r0 - 2 + (e >> 8);
+      const int col = strip * STRIP_W - STRIP_HALO + (e & 255);
+      if (row >= 0 && row < H && col >= 0 && col < W)
+        blur_s[e] = (unsigned char)gauss_chain_px(frame_base, p.in_pitch, W, H, row, col);
+    }
+  }
+  wave_lds_sync();
 
   // ------------------------------------------------------------------ phase 2: blur -> bit planes
   // Sobel is separable: per blur row d = b[+1]-b[-1], s = b[-1]+2b[0]+b[+1] (packed i16 pairs), then
   // sumX(i) = d[i-1]+2d[i]+d[i+1], sumY(i) = s[i-1]-s[i+1] (cannyEdgeD.cu:158-167).
   // S = sumX^2+sumY^2 by one v_dot2 per pixel; comparisons of the reference's float gradient are
   // comparisons of S (strictly monotone, tests).  Direction bins (cannyEdgeD.cu:239-264) exactly:
-  // with X2=sumX^2, Q=sumX*sumY, D=X2-(S-X2):  |2Q| < |D| -> axis bin (D>0: 2 horizontal, D<0: 0
-  // vertical) else diagonal (Q<0: bin 3, else bin 1).
-  u32 dA[2] = { 0, 0 }, dB[2] = { 0, 0 }, sA[2] = { 0, 0 }, sB[2] = { 0, 0 };  // (k-2), (k-1) rows of d and s
-  u32 Su[6], Sc[6], Sd[6];   // S rows: [0]=left neighbour, [1..4]=own 4 px, [5]=right neighbour
-  u32 Vc[4], Vd[4];          // packed (sumX,sumY) of the centre / newest row
+  // with D = sumX^2-sumY^2 and Q = sumX*sumY (two more dot products on the packed pair):
+  //   E1 = D-2Q, E2 = D+2Q;  both > 0: bin 2 (horizontal), both <= 0: bin 0 (vertical),
+  //   E1 > 0 >= E2: bin 3, E2 > 0 >= E1: bin 1   (|2Q| < |D| decides axis vs diagonal; no atan2).
+  // All rings below are indexed by compile-time constants (the row loop is unrolled by 6 = lcm(2,3)).
+  u32 dr[2][2], sr[2][2];  // d and s of the two previous blur rows, [ring][pair]
+  u32 Sr[3][6];            // S rows: [ring][0]=left neighbour, [1..4]=own 4 px, [5]=right neighbour
+  u32 Vr[2][4];            // packed (sumX,sumY) of the two newest Sobel rows
 #pragma unroll
-  for (int k = 0; k < 6; ++k) Su[k] = Sc[k] = Sd[k] = 0;
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-  for (int k = 0; k < 4; ++k) Vc[k] = Vd[k] = 0;
+    for (int b = 0; b < 2; ++b) dr[a][b] = sr[a][b] = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) Sr[a][b] = 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Vr[a][b] = 0;
 
-  // lanes / pixel slots that may be written: valid lane, column inside the image
-  u64 okm[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) okm[k] = __ballot(vm[k] != 0) & BM_VALID;
-  u64 *bm_strip = p.bm + ((size_t)(frame * p.nstrips + strip) * H) * BM_WORDS;
+  // this strip's 31 bytes of each bit-plane row: lane pair (2b+1, 2b+2) -> byte b
+  const size_t plane_off = (size_t)frame * H * p.RD * 4 + (size_t)strip * 31 + (size_t)((lane - 1) >> 1);
+  uint8_t *srow = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
+  uint8_t *crow = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
+  const bool store_lane = (lane & 1) && lane < 63;
+  const u32 a_lo0 = p.a_lo[0], a_hi0 = p.a_hi[0];
 
-  for (int k = r0 - 2; k < r0 + CHUNK + 2; ++k) {  // k = blur row arriving
-    const u32 b = reinterpret_cast<const u32 *>(blur_s)[(k - (r0 - 2)) * 64 + lane];
-    const u32 A = unpack_lo(b), B = unpack_hi(b);
-    const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
-    const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
-    const i16x2 two = { 2, 2 };
-    u32 dk[2], sk[2];
-    dk[0] = R(I(p1) - I(m1));
-    sk[0] = R(I(A) * two + (I(m1) + I(p1)));
-    dk[1] = R(I(p3) - I(p1));
-    sk[1] = R(I(B) * two + (I(p1) + I(p3)));
-    // Sobel row i = k-1
-    const int i = k - 1;
+  constexpr int NSTEPS = CHUNK + 4;
+#pragma nounroll
+  for (int t0 = 0; t0 < NSTEPS; t0 += 6) {
 #pragma unroll
-    for (int q = 0; q < 6; ++q) { Su[q] = Sc[q]; Sc[q] = Sd[q]; }
+    for (int u = 0; u < 6; ++u) {
+      const int t = t0 + u;
+      if (t >= NSTEPS) break;
+      const int k = r0 - 2 + t;  // blur row arriving
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int rn = u % 2, rp = (u + 1) % 2;            // d/s ring: new row -> [rn] (holds row k-2), previous row k-1 in [rp]
+      const int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;  // S ring: new / centre / up
+      const u32 b = reinterpret_cast<const u32 *>(blur_s)[t * 64 + lane];
+      const u32 A = unpack_lo(b), B = unpack_hi(b);
+      const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
+      const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
+      const i16x2 two = { 2, 2 };
+      u32 dk[2], sk[2];
+      dk[0] = R(I(p1) - I(m1));
+      sk[0] = R(I(A) * two + (I(m1) + I(p1)));
+      dk[1] = R(I(p3) - I(p1));
+      sk[1] = R(I(B) * two + (I(p1) + I(p3)));
+      // Sobel row i = k-1 from blur rows k-2 (ring rn), k-1 (ring rp), k (new)
+      const int i = k - 1;
+      if (i >= 0 && i < H) {  // wave-uniform
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Vc[q] = Vd[q];
-    if (i >= 0 && i < H) {  // wave-uniform
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const u32 X = R(I(dA[h]) + I(dk[h]) + I(dB[h]) * two);
-        const u32 Y = R(I(sA[h]) - I(sk[h]));
-        Vd[2 * h + 0] = __builtin_amdgcn_perm(Y, X, 0x05040100u);  // (sumX, sumY) of pixel 2h
-        Vd[2 * h + 1] = __builtin_amdgcn_perm(Y, X, 0x07060302u);  // pixel 2h+1
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) Sd[1 + q] = (u32)__builtin_amdgcn_sdot2(I(Vd[q]), I(Vd[q]), 0, false) & vm[q];
-    } else {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { Sd[1 + q] = 0; Vd[q] = 0; }
-    }
-    Sd[0] = from_lane_below(Sd[4]);
-    Sd[5] = from_lane_above(Sd[1]);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) { dA[h] = dB[h]; dB[h] = dk[h]; sA[h] = sB[h]; sB[h] = sk[h]; }
-
-    // NMS + thresholds for row c = k-2
-    const int c = k - 2;
-    if (c >= r0 && c < H) {  // wave-uniform (c < r0 + CHUNK by the loop bound)
-      u64 strong[4], cand[4];
-      const u32 mx = max(max(Sc[1], Sc[2]), max(Sc[3], Sc[4]));
-      const bool wrap = __ballot(mx >= p.wrap_limit) != 0;  // some gradient >= 256: u8 wrap bands needed
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const u32 g = Sc[1 + q];
-        const int sx = (int)(short)(Vc[q] & 0xFFFFu), sy = (int)(short)(Vc[q] >> 16);
-        const int X2 = sx * sx, Q2 = 2 * sx * sy;
-        const int D = 2 * X2 - (int)g;
-        const u64 e1p = __ballot(D - Q2 > 0), e2p = __ballot(D + Q2 > 0);
-        const u64 e1n = __ballot(D - Q2 < 0), e2n = __ballot(D + Q2 < 0);
-        const u64 b2 = e1p & e2p, b0 = e1n & e2n;
-        const u64 dg = ~(b0 | b2);
-        const u64 qneg = __ballot(Q2 < 0);
-        const u64 b3 = dg & qneg, b1 = dg & ~qneg;
-        // neighbours (cannyEdgeD.cu:245-264): bin0 down/up, bin1 down-left/up-right, bin2 right/left, bin3 up-left/down-right
-        const u64 k0 = __ballot(max(Sd[1 + q], Su[1 + q]) <= g);
-        const u64 k1 = __ballot(max(Sd[q], Su[2 + q]) <= g);
-        const u64 k2 = __ballot(max(Sc[2 + q], Sc[q]) <= g);
-        const u64 k3 = __ballot(max(Su[q], Sd[2 + q]) <= g);
-        const u64 keep = (b0 & k0) | (b1 & k1) | (b2 & k2) | (b3 & k3);
-        u64 cl, st;
-        if (!wrap) {
-          cl = __ballot(g >= p.a_lo[0]);
-          st = __ballot(g >= p.a_hi[0]);
-        } else {
-          const u64 w0 = __ballot(g >= 262144u), w1 = __ballot(g >= 1048576u);
-          cl = (__ballot(g >= p.a_lo[0]) & ~w0) | (__ballot(g >= p.a_lo[1]) & ~w1) | __ballot(g >= p.a_lo[2]);
-          st = (__ballot(g >= p.a_hi[0]) & ~w0) | (__ballot(g >= p.a_hi[1]) & ~w1) | __ballot(g >= p.a_hi[2]);
+        for (int h = 0; h < 2; ++h) {
+          const u32 pm = h == 0 ? pm0 : pm1;  // sums outside the image are 0 (zero padding of every stage)
+          const u32 X = R(I(dr[rn][h]) + I(dk[h]) + I(dr[rp][h]) * two) & pm;
+          const u32 Y = R(I(sr[rn][h]) - I(sk[h])) & pm;
+          Vr[rn][2 * h + 0] = __builtin_amdgcn_perm(Y, X, 0x05040100u);  // (sumX, sumY) of pixel 2h
+          Vr[rn][2 * h + 1] = __builtin_amdgcn_perm(Y, X, 0x07060302u);  // pixel 2h+1
         }
-        cand[q] = cl & keep & okm[q];
-        strong[q] = st & keep & okm[q];
-      }
-      u64 wv = 0;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        wv = lane == q ? strong[q] : wv;
-        wv = lane == 4 + q ? cand[q] : wv;
+        for (int q = 0; q < 4; ++q) Sr[sN][1 + q] = (u32)__builtin_amdgcn_sdot2(I(Vr[rn][q]), I(Vr[rn][q]), 0, false);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { Sr[sN][1 + q] = 0; Vr[rn][q] = 0; }
       }
-      if (lane < BM_WORDS) bm_strip[(size_t)c * BM_WORDS + lane] = wv;
+      Sr[sN][0] = from_lane_below(Sr[sN][4]);
+      Sr[sN][5] = from_lane_above(Sr[sN][1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
+
+      // NMS + thresholds for row c = k-2: centre ring sC (its V is in Vr[rp]), up sU, down sN
+      const int c = k - 2;
+      if (c >= r0 && c < H) {  // wave-uniform (c < r0 + CHUNK by the step count)
+        u32 nib = 0;
+        const u32 mx = max(max(Sr[sC][1], Sr[sC][2]), max(Sr[sC][3], Sr[sC][4]));
+        if (__ballot(mx >= a_lo0) != 0) {  // rows without a single candidate skip direction + NMS
+          const bool wrap = __ballot(mx >= p.wrap_limit) != 0;  // some gradient >= 256: u8 wrap bands needed
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32 g = Sr[sC][1 + q];
+            const u32 V = Vr[rp][q];
+            const i16x2 pm = { 1, -1 };
+            const int D = __builtin_amdgcn_sdot2(I(V), I(V) * pm, 0, false);
+            const int Q = __builtin_amdgcn_sdot2(I(V), I(V >> 16), 0, false);
+            const u64 p1m = __ballot(D - 2 * Q > 0), p2m = __ballot(D + 2 * Q > 0);
+            // neighbours (cannyEdgeD.cu:245-264): bin0 down/up, bin1 down-left/up-right, bin2 right/left, bin3 up-left/down-right
+            const u64 k0 = __ballot(max(Sr[sN][1 + q], Sr[sU][1 + q]) <= g);
+            const u64 k1 = __ballot(max(Sr[sN][q], Sr[sU][2 + q]) <= g);
+            const u64 k2 = __ballot(max(Sr[sC][2 + q], Sr[sC][q]) <= g);
+            const u64 k3 = __ballot(max(Sr[sU][q], Sr[sN][2 + q]) <= g);
+            const u64 keep = (~p1m & ~p2m & k0) | (~p1m & p2m & k1) | (p1m & p2m & k2) | (p1m & ~p2m & k3);
+            u64 cl, st;
+            if (!wrap) {
+              cl = __ballot(g >= a_lo0);
+              st = __ballot(g >= a_hi0);
+            } else {
+              const u64 w0 = __ballot(g >= 262144u), w1 = __ballot(g >= 1048576u);
+              cl = (__ballot(g >= a_lo0) & ~w0) | (__ballot(g >= p.a_lo[1]) & ~w1) | __ballot(g >= p.a_lo[2]);
+              st = (__ballot(g >= a_hi0) & ~w0) | (__ballot(g >= p.a_hi[1]) & ~w1) | __ballot(g >= p.a_hi[2]);
+            }
+            // per-lane nibbles (bit q = pixel slot q): strong in bits 0..3, candidate in bits 8..11
+            nib |= __builtin_amdgcn_inverse_ballot_w64(st & keep) ? (1u << q) : 0u;
+            nib |= __builtin_amdgcn_inverse_ballot_w64(cl & keep) ? (0x100u << q) : 0u;
+          }
+          nib &= oknib;
+        }
+        const u32 w = nib | (from_lane_above(nib) << 4);  // bits 0..7 strong byte, 8..15 candidate byte
+        if (store_lane) {
+          srow[(size_t)c * p.RD * 4] = (uint8_t)w;
+          crow[(size_t)c * p.RD * 4] = (uint8_t)(w >> 8);
+        }
+      }
     }
   }
 }
@@ -380,176 +434,378 @@ hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s)
 __global__ __launch_bounds__(256) void k_pack(const PackParams p)
 {
   const int lane = threadIdx.x & 63;
+  const int segs = (p.W + 255) / 256;  // 256 px (64 lanes x 4) per wave
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long total = (long long)p.nframes * p.nstrips * p.H;
+  const long long total = (long long)p.nframes * p.H * segs;
   if (wave >= total) return;
-  const int row = (int)(wave % p.H);
-  const int strip = (int)((wave / p.H) % p.nstrips);
-  const int frame = (int)(wave / ((long long)p.H * p.nstrips));
-  const int c0 = strip * STRIP_W - STRIP_HALO + lane * PX_PER_LANE;
+  const int seg = (int)(wave % segs);
+  const int row = (int)((wave / segs) % p.H);
+  const int frame = (int)(wave / ((long long)segs * p.H));
+  const int c0 = seg * 256 + lane * 4;
   const uint8_t *rowp = p.in + (size_t)frame * p.in_frame_stride + (size_t)row * p.in_pitch;
-  u64 wv = 0;
+  u32 nib = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int col = c0 + k;
-    const bool in = col >= 0 && col < p.W && lane >= 1 && lane <= 62;
-    const u32 v = in ? rowp[col] : 0u;
-    const u64 st = __ballot(v == 255u), cd = __ballot(v >= 128u);
-    wv = lane == k ? st : wv;
-    wv = lane == 4 + k ? cd : wv;
+    const u32 v = (c0 + k < p.W) ? rowp[c0 + k] : 0u;
+    nib |= (v == 255u) ? (1u << k) : 0u;
+    nib |= (v >= 128u) ? (0x100u << k) : 0u;
   }
-  if (lane < BM_WORDS) p.bm[(((size_t)frame * p.nstrips + strip) * p.H + row) * BM_WORDS + lane] = wv;
+  const u32 w = nib | (from_lane_above(nib) << 4);
+  const size_t off = ((size_t)frame * p.H + row) * p.RD * 4 + (size_t)seg * 32 + (size_t)(lane >> 1);
+  if (!(lane & 1) && (size_t)seg * 32 + (size_t)(lane >> 1) < (size_t)p.RD * 4) {
+    reinterpret_cast<uint8_t *>(p.sbits)[off] = (uint8_t)w;
+    reinterpret_cast<uint8_t *>(p.cbits)[off] = (uint8_t)(w >> 8);
+  }
 }
 
 hipError_t launch_pack(const PackParams &p, hipStream_t s)
 {
-  const long long total = (long long)p.nframes * p.nstrips * p.H;
+  const long long total = (long long)p.nframes * p.H * ((p.W + 255) / 256);
   hipLaunchKernelGGL(k_pack, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, p);
   return hipGetLastError();
 }
 
 // =================================================================================================
-// k_hyst: hysteresis on the bit planes
+// k_hyst: edge hysteresis on the bit planes, by row sweeps with carry look-ahead
 // =================================================================================================
-// Workgroup = (frame, strip, row tile); lane = one row, holding its 4 strong + 4 candidate words in
-// registers.  A candidate with a strong 8-neighbour becomes strong (cannyEdgeD.cu:342-352); here
-// 64 columns per 64-bit op.  Column neighbours in the 4-way interleaved plane layout: slot j-1 / j+1,
-// across the lane boundary a 1-bit shift of slot 3 / slot 0.  Row neighbours: the adjacent lane
-// (wave edges through LDS).  The tile iterates to its local fixpoint; cross-tile propagation happens
-// over successive launches, gated by a device-side flag (no host round trip, unlike
-// cannyEdgeH.cu:307-324).  The fixpoint is unique (monotone updates), so tiling cannot change it.
-static __device__ __forceinline__ u64 load_strong(const u64 *bm, int H, int nstrips, int frame, int strip, int row, int j)
+// A candidate with a strong 8-neighbour becomes strong, to the fixpoint (cannyEdgeD.cu:342-352,
+// launch loop cannyEdgeH.cu:307-324).  Work item = (frame, tile of tile_rows rows), one per wave;
+// a whole bit-plane row lives in the wave (lane l holds dwords l*NW .. l*NW+NW-1).  The wave sweeps
+// its rows downwards, then upwards: row r takes the strong bits of the previous row dilated by one
+// column each way, ANDs with its candidates, and then FILLS every candidate run touched by a strong
+// bit along the whole row at once: adding the seeds to the candidate word ripples a carry through
+// each run ((c + s) ^ c marks the bits above the seed), lanes are chained by a carry look-ahead over
+// the per-lane generate/propagate ballots (one 64-bit scalar add), and the bit-reversed pass fills
+// the other direction.  One down+up pair settles every path that is monotone in the row index, so
+// a tile converges in a few sweeps however long its chains are -- unlike pixel-per-iteration
+// propagation (the reference moves one 30x30 tile per launch).  Tiles exchange boundary rows across
+// launches; per-tile change flags let later launches touch only the tiles next to a change, and the
+// flag word of the last queued launch tells the host whether the fixpoint was reached.
+template <int NW>
+struct RowBits {
+  u32 w[NW];
+};
+
+template <int NW>
+static __device__ __forceinline__ RowBits<NW> row_load(const u32 *plane_row, int lane, int RD)
 {
-  // own word plus the two halo bits taken from the neighbouring strips (bit 0 <- their bit 62, bit 63 <- their bit 1)
-  if (row < 0 || row >= H) return 0;
-  const size_t base = (((size_t)frame * nstrips + strip) * H + row) * BM_WORDS + j;
-  u64 v = bm[base] & BM_VALID;
-  if (strip > 0) v |= (bm[base - (size_t)H * BM_WORDS] >> 62) & 1ull;
-  if (strip + 1 < nstrips) v |= ((bm[base + (size_t)H * BM_WORDS] >> 1) & 1ull) << 63;
-  return v;
+  RowBits<NW> r;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const int d = lane * NW + i;
+    r.w[i] = d < RD ? plane_row[d] : 0u;
+  }
+  return r;
 }
 
+// fill every run of `c` that contains a bit of `s` (s subset of c), over the whole row
+template <int NW>
+static __device__ __forceinline__ RowBits<NW> row_fill(const RowBits<NW> &c, const RowBits<NW> &s)
+{
+  RowBits<NW> out;
+  // towards higher columns
+  {
+    u32 t[NW];
+    u32 carry = 0;
+    bool allones = true;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const u64 x = (u64)c.w[i] + s.w[i] + carry;
+      t[i] = (u32)x;
+      carry = (u32)(x >> 32);
+      allones = allones && (t[i] == 0xFFFFFFFFu);
+    }
+    const u64 G = __ballot(carry != 0), P = __ballot(allones);
+    const u64 A = G | P;
+    const u64 cin = (A + G) ^ A ^ G;  // carry into each lane (look-ahead by one scalar add)
+    carry = __builtin_amdgcn_inverse_ballot_w64(cin) ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const u64 x = (u64)c.w[i] + s.w[i] + carry;
+      carry = (u32)(x >> 32);
+      out.w[i] = (((u32)x ^ c.w[i]) & c.w[i]) | s.w[i];
+    }
+  }
+  // towards lower columns: the same on the bit-reversed row (lane order reversed in the look-ahead)
+  {
+    u32 rc[NW], rs[NW], t[NW];
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      rc[i] = __builtin_bitreverse32(c.w[NW - 1 - i]);
+      rs[i] = __builtin_bitreverse32(s.w[NW - 1 - i]);
+    }
+    u32 carry = 0;
+    bool allones = true;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const u64 x = (u64)rc[i] + rs[i] + carry;
+      t[i] = (u32)x;
+      carry = (u32)(x >> 32);
+      allones = allones && (t[i] == 0xFFFFFFFFu);
+    }
+    const u64 G = __builtin_bitreverse64(__ballot(carry != 0)), P = __builtin_bitreverse64(__ballot(allones));
+    const u64 A = G | P;
+    const u64 cin = __builtin_bitreverse64((A + G) ^ A ^ G);
+    carry = __builtin_amdgcn_inverse_ballot_w64(cin) ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) {
+      const u64 x = (u64)rc[i] + rs[i] + carry;
+      carry = (u32)(x >> 32);
+      const u32 f = (((u32)x ^ rc[i]) & rc[i]);
+      out.w[NW - 1 - i] |= __builtin_bitreverse32(f);
+    }
+  }
+  return out;
+}
+
+// strong bits of the neighbouring row, dilated by one column each way
+template <int NW>
+static __device__ __forceinline__ RowBits<NW> row_dilate(const RowBits<NW> &p)
+{
+  RowBits<NW> d;
+  const u32 below = from_lane_below(p.w[NW - 1]);  // previous lane's last dword
+  const u32 above = from_lane_above(p.w[0]);       // next lane's first dword
+#pragma unroll
+  for (int i = 0; i < NW; ++i) {
+    const u32 lo = i == 0 ? below : p.w[i - 1];
+    const u32 hi = i == NW - 1 ? above : p.w[i + 1];
+    d.w[i] = p.w[i] | __builtin_amdgcn_alignbit(p.w[i], lo, 31) | __builtin_amdgcn_alignbit(hi, p.w[i], 1);
+  }
+  return d;
+}
+
+// Workgroup tile = 4 waves x TR rows (TR <= 64), C rows and S rows (+2 boundary rows owned by the
+// neighbouring workgroups) staged in LDS; each row 64*NW dwords.
+static inline int hyst_nw(int RD) { return RD <= 64 ? 1 : RD <= 128 ? 2 : 4; }
+size_t hyst_lds_bytes(int RD, int block_rows) { return (size_t)(2 * block_rows + 2) * 64 * hyst_nw(RD) * 4 + 128; }
+
+template <int NW>
 __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
 {
-  if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed nothing visible: fixpoint reached
+  if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  u64 *edge = reinterpret_cast<u64 *>(smem);  // [wave][2][4]
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-  const int rt = blockIdx.x % p.nrtiles;
-  const int strip = (blockIdx.x / p.nrtiles) % p.nstrips;
-  const int frame = blockIdx.x / (p.nrtiles * p.nstrips);
-  const int H = p.H;
-  const int row = rt * p.tile_rows + (int)threadIdx.x;
-  const bool rv = row < H && (int)threadIdx.x < p.tile_rows;
-
-  u64 S[4], C[4], S0[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    S[j] = rv ? load_strong(p.bm, H, p.nstrips, frame, strip, row, j) : 0;
-    C[j] = rv ? (p.bm[(((size_t)frame * p.nstrips + strip) * H + row) * BM_WORDS + 4 + j] & BM_VALID) : 0;
-    S0[j] = S[j];
+  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int bt = blockIdx.x % p.nrtiles, frame = blockIdx.x / p.nrtiles;
+  const int H = p.H, RD = p.RD, TR = p.tile_rows, BR = nwaves * TR;
+  const int b0 = bt * BR, nb = min(H, b0 + BR) - b0;  // rows of this workgroup tile
+  uint8_t *tf_prev = p.tflags + (size_t)((p.iter + 1) & 1) * p.nframes * p.nrtiles + (size_t)frame * p.nrtiles;
+  uint8_t *tf_cur = p.tflags + (size_t)(p.iter & 1) * p.nframes * p.nrtiles + (size_t)frame * p.nrtiles;
+  bool top = false, bot = false;
+  if (p.iter > 0) {
+    // work only if a neighbouring tile changed the row this tile looks at
+    top = bt > 0 && (tf_prev[bt - 1] & 2);
+    bot = bt + 1 < p.nrtiles && (tf_prev[bt + 1] & 1);
+    if (!top && !bot) {  // uniform for the workgroup
+      if (threadIdx.x == 0) tf_cur[bt] = 0;
+      return;
+    }
   }
-  // rows just outside the tile (owned by other tiles; constant during this launch)
-  u64 halo_top[4] = { 0, 0, 0, 0 }, halo_bot[4] = { 0, 0, 0, 0 };
-  if (threadIdx.x == 0)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) halo_top[j] = load_strong(p.bm, H, p.nstrips, frame, strip, rt * p.tile_rows - 1, j);
-  if ((int)threadIdx.x == p.tile_rows - 1)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) halo_bot[j] = load_strong(p.bm, H, p.nstrips, frame, strip, rt * p.tile_rows + p.tile_rows, j);
+  // this wave's rows inside the workgroup tile
+  const int w0 = min(wib * TR, nb), n = min((wib + 1) * TR, nb) - w0;
+  const u64 all_rows = n >= 64 ? ~0ull : ((1ull << n) - 1);
+  u64 dirty;  // bit r = row b0 + w0 + r needs (re)evaluation
+  if (p.iter > 0) dirty = ((top && w0 == 0 && n > 0) ? 1ull : 0ull) | ((bot && w0 + n == nb && n > 0) ? (1ull << (n - 1)) : 0ull);
+  else dirty = all_rows;
+  u64 unfilled = p.first_pass ? all_rows : 0ull;  // rows not yet closed under the in-row fill
 
-  for (int it = 0; it < 100000; ++it) {
-    if (lane == 0)
+  constexpr int ROWW = 64 * NW;  // dwords per LDS row
+  u32 *Cl = reinterpret_cast<u32 *>(smem);
+  u32 *Sl = Cl + (size_t)BR * ROWW;                  // rows -1 .. BR  ->  index 0 .. BR+1
+  u32 *bchg = Sl + (size_t)(BR + 2) * ROWW;          // per-wave boundary-change bits of the current round
+  u32 *S = p.sbits + (size_t)frame * H * RD;
+  const u32 *C = p.cbits + (size_t)frame * H * RD;
+  // stage the tile: rows dealt to the waves round-robin, 8 loads in flight per wave
+  for (int rb = wib * 8; rb < nb + 2; rb += 8 * nwaves) {
+    RowBits<NW> cv[8], sv[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) edge[(wave * 2 + 0) * 4 + j] = S[j];
-    if (lane == 63)
+    for (int k = 0; k < 8; ++k) {
+      const int r = rb + k - 1;  // -1 .. nb
+      const int gr = b0 + r;
+      const bool inS = r <= nb && gr >= 0 && gr < H, inC = r >= 0 && r < nb;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) edge[(wave * 2 + 1) * 4 + j] = S[j];
+      for (int i = 0; i < NW; ++i) { cv[k].w[i] = 0; sv[k].w[i] = 0; }
+      if (inS) sv[k] = row_load<NW>(S + (size_t)gr * RD, lane, RD);
+      if (inC) cv[k] = row_load<NW>(C + (size_t)gr * RD, lane, RD);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int r = rb + k - 1;
+      if (r <= nb)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) Sl[(r + 1) * ROWW + lane * NW + i] = sv[k].w[i];
+      if (r >= 0 && r < nb)
+#pragma unroll
+        for (int i = 0; i < NW; ++i) Cl[r * ROWW + lane * NW + i] = cv[k].w[i];
+    }
+  }
+  if (threadIdx.x < 32) bchg[threadIdx.x] = 0;
+  __syncthreads();
+
+  // Row worklist per wave, lowest dirty row first: a downward sweep that steps back up whenever a
+  // row's new strong bits reach candidates of the row above.  Work is proportional to the rows that
+  // change.  Waves exchange their boundary rows through the shared LDS tile between rounds.
+  u64 changed = 0;
+  auto lds_row = [&](const u32 *base, int idx) {
+    RowBits<NW> v;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) v.w[i] = base[idx * ROWW + lane * NW + i];
+    return v;
+  };
+  for (int round = 0; round < 4096; ++round) {
+    u64 round_changed = 0;
+    while (dirty) {
+      const int r = __builtin_ctzll(dirty);
+      dirty &= dirty - 1;
+      const int br = w0 + r;  // row inside the workgroup tile
+      const RowBits<NW> up = lds_row(Sl, br), s = lds_row(Sl, br + 1), dn = lds_row(Sl, br + 2), c = lds_row(Cl, br);
+      RowBits<NW> nbr;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) nbr.w[i] = up.w[i] | dn.w[i];
+      const RowBits<NW> d = row_dilate<NW>(nbr);
+      RowBits<NW> seed;
+      bool grew = false, hs = false, hc = false;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) {
+        seed.w[i] = s.w[i] | (c.w[i] & d.w[i]);
+        grew = grew || (seed.w[i] != s.w[i]);
+        hs = hs || s.w[i] != 0;
+        hc = hc || (c.w[i] & ~s.w[i]) != 0;
+      }
+      bool todo = __ballot(grew) != 0;
+      if ((unfilled >> r) & 1) {
+        unfilled &= ~(1ull << r);
+        todo = todo || (__ballot(hs) != 0 && __ballot(hc) != 0);
+      }
+      if (!todo) continue;
+      const RowBits<NW> f = row_fill<NW>(c, seed);
+      bool ch = false;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) ch = ch || (f.w[i] != s.w[i]);
+      if (__ballot(ch) == 0) continue;
+#pragma unroll
+      for (int i = 0; i < NW; ++i) Sl[(br + 1) * ROWW + lane * NW + i] = f.w[i];
+      wave_lds_sync();
+      round_changed |= 1ull << r;
+      dirty |= ((1ull << r) >> 1) | (((1ull << r) << 1) & all_rows);
+    }
+    changed |= round_changed;
+    if (lane == 0) bchg[wib] = (n > 0 && (round_changed & 1ull) ? 1u : 0u) | (n > 0 && ((round_changed >> (n - 1)) & 1ull) ? 2u : 0u);
     __syncthreads();
-    u64 N[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      u64 up = __shfl_up(S[j], 1), dn = __shfl_down(S[j], 1);
-      if (lane == 0) up = wave > 0 ? edge[((wave - 1) * 2 + 1) * 4 + j] : halo_top[j];
-      if (lane == 63) dn = wave + 1 < nw ? edge[((wave + 1) * 2 + 0) * 4 + j] : halo_bot[j];
-      if ((int)threadIdx.x == p.tile_rows - 1) dn = halo_bot[j];
-      N[j] = S[j] | up | dn;
+    if (n > 0) {
+      if (wib > 0 && (bchg[wib - 1] & 2u)) dirty |= 1ull;
+      if (wib + 1 < nwaves && (bchg[wib + 1] & 1u)) dirty |= 1ull << (n - 1);
     }
-    u64 T[4];
-    T[0] = S[0] | (C[0] & (N[0] | (N[3] << 1) | N[1]));
-    T[1] = S[1] | (C[1] & (N[1] | N[0] | N[2]));
-    T[2] = S[2] | (C[2] & (N[2] | N[1] | N[3]));
-    T[3] = S[3] | (C[3] & (N[3] | N[2] | (N[0] >> 1)));
-    // in-row propagation, 16 px each way per iteration
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      T[1] |= C[1] & T[0]; T[2] |= C[2] & T[1]; T[3] |= C[3] & T[2]; T[0] |= C[0] & (T[3] << 1);
-      T[2] |= C[2] & T[3]; T[1] |= C[1] & T[2]; T[0] |= C[0] & T[1]; T[3] |= C[3] & (T[0] >> 1);
-    }
-    const bool ch = (T[0] != S[0]) | (T[1] != S[1]) | (T[2] != S[2]) | (T[3] != S[3]);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) S[j] = T[j];
-    if (!__syncthreads_or(ch)) break;
+    // workgroup-wide "any wave has work": OR through an LDS word per round parity
+    // (no __syncthreads_or: its hidden static LDS would shift the dynamic region)
+    if (lane == 0 && dirty != 0) atomicOr(&bchg[18 + (round & 1)], 1u);
+    __syncthreads();
+    const bool more = bchg[18 + (round & 1)] != 0;
+    if (threadIdx.x == 0) bchg[18 + ((round + 1) & 1)] = 0;
+    if (!more) break;
   }
 
-  // write back; tell the next launch whether anything another tile reads has changed:
-  // columns 1 and 62 of any row (the neighbouring strips' halo bits) or the first / last tile row
-  bool vis = false;
-  if (rv) {
-    const u64 edge_cols = (1ull << 1) | (1ull << 62);
-    const bool edge_row = threadIdx.x == 0 || (int)threadIdx.x == p.tile_rows - 1;
+  // write back the rows that changed; tell the neighbouring workgroups through the tile flags
+  for (u64 m = changed; m; m &= m - 1) {
+    const int r = __builtin_ctzll(m);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const u64 diff = (S[j] ^ S0[j]) & BM_VALID;
-      if (diff) p.bm[(((size_t)frame * p.nstrips + strip) * H + row) * BM_WORDS + j] = S[j] & BM_VALID;
-      vis |= (diff & (edge_row ? BM_VALID : edge_cols)) != 0;
+    for (int i = 0; i < NW; ++i) {
+      const int dd = lane * NW + i;
+      if (dd < RD) S[(size_t)(b0 + w0 + r) * RD + dd] = Sl[(w0 + r + 1) * ROWW + lane * NW + i];
     }
   }
-  if (__syncthreads_or(vis) && threadIdx.x == 0) atomicOr(&p.flags[p.iter], 1u);
+  const bool first_changed = n > 0 && w0 == 0 && (changed & 1ull);
+  const bool last_changed = n > 0 && w0 + n == nb && ((changed >> (n - 1)) & 1ull);
+  if (lane == 0 && (first_changed || last_changed)) atomicOr(&bchg[16], (first_changed ? 1u : 0u) | (last_changed ? 2u : 0u));
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const u32 vis = bchg[16];
+    tf_cur[bt] = (uint8_t)vis;
+    if (vis) atomicOr(&p.flags[p.iter], 1u);
+  }
+  if (lane == 0 && p.stats && n > 0) {  // diagnostics: changed rows summed / max over wave tiles, active wave tiles
+    const u32 nch = (u32)__builtin_popcountll(changed);
+    atomicAdd(&p.stats[0], nch);
+    atomicMax(&p.stats[1], nch);
+    atomicAdd(&p.stats[2], 1u);
+  }
 }
 
 hipError_t launch_hyst(const HystParams &p, hipStream_t s)
 {
-  const int nw = p.tile_rows / 64;
-  hipLaunchKernelGGL(k_hyst, dim3((unsigned)(p.nframes * p.nstrips * p.nrtiles)), dim3(p.tile_rows), (size_t)nw * 2 * 4 * sizeof(u64), s, p);
-  return hipGetLastError();
+  const dim3 grid((unsigned)(p.nframes * p.nrtiles)), block(64 * p.waves);
+  const size_t lds = hyst_lds_bytes(p.RD, p.tile_rows * p.waves);
+  if (p.tile_rows > 64 || p.waves < 1 || p.waves > 16 || lds > 160 * 1024 || p.RD > 256) {
+    fprintf(stderr, "launch_hyst: unsupported geometry lds=%zu RD=%d tile_rows=%d\n", lds, p.RD, p.tile_rows);
+    return hipErrorInvalidValue;
+  }
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hyst<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hyst<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hyst<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_done = true;
+  }
+  const int nw = hyst_nw(p.RD);
+  if (nw == 1) hipLaunchKernelGGL(k_hyst<1>, grid, block, lds, s, p);
+  else if (nw == 2) hipLaunchKernelGGL(k_hyst<2>, grid, block, lds, s, p);
+  else hipLaunchKernelGGL(k_hyst<4>, grid, block, lds, s, p);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    hipFuncAttributes fa{};
+    hipError_t e2 = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_hyst<1>));
+    fprintf(stderr, "k_hyst<1> attrs (%s): static lds %zu, maxDyn %d, regs %d, maxThreads %d\n", hipGetErrorString(e2), fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes, fa.numRegs, fa.maxThreadsPerBlock);
+  }
+  if (e != hipSuccess) fprintf(stderr, "launch_hyst failed: %s grid=%u lds=%zu RD=%d tile_rows=%d nrtiles=%d nframes=%d iter=%d\n", hipGetErrorString(e), grid.x, lds, p.RD, p.tile_rows, p.nrtiles, p.nframes, p.iter);
+  return e;
 }
 
 // =================================================================================================
 // k_expand: strong plane -> u8 edge map (255 / 0); candidates left over are dropped here
-// (removeCandidates, cannyEdgeD.cu:379-395).
+// (removeCandidates, cannyEdgeD.cu:379-395).  16 px per lane: one ushort of bits -> one 16-byte store.
 // =================================================================================================
+static __device__ __forceinline__ u32 nibble_to_bytes(u32 nib)
+{
+  // bit k -> byte k = 0xFF: (nib * 0x00204081) & 0x01010101 spreads the 4 bits to byte positions
+  const u32 x = (nib * 0x00204081u) & 0x01010101u;
+  return (x << 8) - x;
+}
+
+template <bool ALIGN16>
 __global__ __launch_bounds__(256) void k_expand(const ExpandParams p)
 {
   const int lane = threadIdx.x & 63;
+  const int segs = (p.W + 1023) / 1024;  // 1024 px (64 lanes x 16) per wave
   const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long total = (long long)p.nframes * p.nstrips * p.H;
+  const long long total = (long long)p.nframes * p.H * segs;
   if (wave >= total) return;
-  // consecutive waves walk the strips of one row, then the next row: contiguous output
-  const int strip = (int)(wave % p.nstrips);
-  const int row = (int)((wave / p.nstrips) % p.H);
-  const int frame = (int)(wave / ((long long)p.nstrips * p.H));
-  const u64 *rec = p.bm + (((size_t)frame * p.nstrips + strip) * p.H + row) * BM_WORDS;
-  u32 v = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const u64 w = rec[j];  // wave-uniform address
-    const u32 half = lane < 32 ? (u32)w : (u32)(w >> 32);
-    v |= ((half >> (lane & 31)) & 1u) ? (0xFFu << (8 * j)) : 0u;
-  }
-  if (lane < 1 || lane > 62) return;
-  const int c0 = strip * STRIP_W - STRIP_HALO + lane * PX_PER_LANE;
+  const int seg = (int)(wave % segs);
+  const int row = (int)((wave / segs) % p.H);
+  const int frame = (int)(wave / ((long long)segs * p.H));
+  const int c0 = seg * 1024 + lane * 16;
+  if (c0 >= p.W) return;
+  const unsigned short *bits = reinterpret_cast<const unsigned short *>(p.sbits + ((size_t)frame * p.H + row) * p.RD);
+  const u32 b = bits[c0 >> 4];
   uint8_t *dst = p.out + (size_t)frame * p.out_frame_stride + (size_t)row * p.out_pitch + c0;
-  if (c0 + 3 < p.W) *reinterpret_cast<u32 *>(dst) = v;
-  else
-    for (int k = 0; k < 4; ++k)
-      if (c0 + k < p.W) dst[k] = (uint8_t)(v >> (8 * k));
+  u32 v[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
+  if (c0 + 15 < p.W) {
+    if (ALIGN16) *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+    else
+#pragma unroll
+      for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
+  } else {
+    for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+  }
 }
 
 hipError_t launch_expand(const ExpandParams &p, hipStream_t s)
 {
-  const long long total = (long long)p.nframes * p.nstrips * p.H;
-  hipLaunchKernelGGL(k_expand, dim3((unsigned)((total + 3) / 4)), dim3(256), 0, s, p);
+  const long long total = (long long)p.nframes * p.H * ((p.W + 1023) / 1024);
+  const dim3 grid((unsigned)((total + 3) / 4)), block(256);
+  const bool a16 = (((uintptr_t)p.out | p.out_pitch | p.out_frame_stride) & 15u) == 0;
+  if (a16) hipLaunchKernelGGL(k_expand<true>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(k_expand<false>, grid, block, 0, s, p);
   return hipGetLastError();
 }
 

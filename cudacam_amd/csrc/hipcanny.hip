@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -28,6 +29,7 @@ int fail(int code, const std::string &msg)
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr int MAX_HYST_LAUNCHES = 16;
+constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0..15] launch flags, [16..63] 3 diagnostic words per launch
 }  // namespace
 
 struct hc_ctx {
@@ -42,9 +44,11 @@ struct hc_ctx {
   uint8_t *d_blur = nullptr, *d_nms = nullptr;
   int16_t *d_sx = nullptr, *d_sy = nullptr;
   // fused path
-  u64 *d_bm = nullptr;
+  u32 *d_sbits = nullptr, *d_cbits = nullptr;  // bit planes [max_batch][H][RD]
+  uint8_t *d_tflags = nullptr;
+  int RD = 0;
   u32 *d_flags = nullptr, *h_flags = nullptr;
-  int nstrips = 0, chunk = 0, hyst_launches = 4, tile_rows = 0, nrtiles = 0;
+  int nstrips = 0, chunk = 0, hyst_launches = 6, hyst_waves = 16;
   // deferred convergence check of the last fused run
   bool pending = false;
   HystParams pend_h{};
@@ -53,6 +57,7 @@ struct hc_ctx {
   size_t pend_copy_pitch = 0, pend_copy_fs = 0;
   int pend_n = 0;
   int last_work_launches = 0, last_continued = 0;
+  u32 h_stats[3 * 16] = { 0 };
   int uploaded = 0, last_run_n = 0;
   bool profiling = false;
   // hipEvent ring: 4 events per run (start, after stage 0, after the fused/stage kernels, end)
@@ -129,18 +134,21 @@ int finish_pending(hc_ctx *c)
   const int K = c->hyst_launches;
   int work = 0;
   for (int k = 0; k < K; ++k) work += c->h_flags[k] != 0;
+  std::memcpy(c->h_stats, c->h_flags + MAX_HYST_LAUNCHES, sizeof(c->h_stats));
   c->last_work_launches = std::min(K, work + 1);
   c->last_continued = 0;
   if (c->h_flags[K - 1] == 0) return HC_OK;
   c->last_continued = 1;
   for (int round = 0; round < 1000000; ++round) {
-    HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * MAX_HYST_LAUNCHES, c->stream));
+    HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * FLAG_WORDS, c->stream));
     HystParams hp = c->pend_h;
+    hp.first_pass = 0;
     for (int k = 0; k < K; ++k) {
       hp.iter = k;
+      hp.stats = nullptr;
       HIPCK(launch_hyst(hp, c->stream));
     }
-    HIPCK(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(u32) * MAX_HYST_LAUNCHES, hipMemcpyDeviceToHost, c->stream));
+    HIPCK(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, c->stream));
     HIPCK(hipStreamSynchronize(c->stream));
     for (int k = 0; k < K; ++k) c->last_work_launches += c->h_flags[k] != 0;
     if (c->h_flags[K - 1] == 0) break;
@@ -157,15 +165,26 @@ int run_hyst_expand(hc_ctx *c, uint8_t *out, size_t out_pitch, size_t out_fs, in
 {
   const int K = c->hyst_launches;
   HystParams hp{};
-  hp.bm = c->d_bm; hp.H = c->H; hp.nstrips = c->nstrips; hp.nframes = n; hp.tile_rows = c->tile_rows; hp.nrtiles = c->nrtiles; hp.flags = c->d_flags;
+  hp.sbits = c->d_sbits; hp.cbits = c->d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = c->d_flags; hp.tflags = c->d_tflags;
+  // one workgroup per (frame, tile of `waves` x tile_rows rows) staged in LDS (<= 150 KB)
+  {
+    int br = 256;  // rows per workgroup tile
+    while (br > 32 && hyst_lds_bytes(c->RD, br) > 150 * 1024) br /= 2;
+    while (br > 32 && br / 2 >= c->H) br /= 2;  // small frames: do not stage empty rows
+    hp.waves = c->hyst_waves;
+    hp.tile_rows = br / hp.waves;
+    hp.nrtiles = (c->H + br - 1) / br;
+  }
+  hp.first_pass = 1;
   for (int k = 0; k < K; ++k) {
     hp.iter = k;
+    hp.stats = c->d_flags + MAX_HYST_LAUNCHES + 3 * k;
     HIPCK(launch_hyst(hp, c->stream));
   }
   ExpandParams ep{};
-  ep.bm = c->d_bm; ep.out = out; ep.out_pitch = out_pitch; ep.out_frame_stride = out_fs; ep.W = c->W; ep.H = c->H; ep.nstrips = c->nstrips; ep.nframes = n;
+  ep.sbits = c->d_sbits; ep.RD = c->RD; ep.out = out; ep.out_pitch = out_pitch; ep.out_frame_stride = out_fs; ep.W = c->W; ep.H = c->H; ep.nframes = n;
   HIPCK(launch_expand(ep, c->stream));
-  HIPCK(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(u32) * MAX_HYST_LAUNCHES, hipMemcpyDeviceToHost, c->stream));
+  HIPCK(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, c->stream));
   c->pending = true;
   c->pend_h = hp;
   c->pend_e = ep;
@@ -209,12 +228,12 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   } else if (stage == HC_STAGE_MONO) {
     if (int rc = copy_frames_d2d(c, dst, dp, dfs, src, sp, sfs, (size_t)W, n)) return rc;
   }
-  if (stage == HC_STAGE_HYSTER) HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * MAX_HYST_LAUNCHES, c->stream));
+  if (stage == HC_STAGE_HYSTER) HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * FLAG_WORDS, c->stream));
   if (prof) HIPCK(hipEventRecord(c->ev[1], c->stream));
 
   if (stage == HC_STAGE_HYSTER) {
     FrontParams fp{};
-    fp.in = mono; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.bm = c->d_bm; fp.W = W; fp.H = H;
+    fp.in = mono; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = c->d_sbits; fp.cbits = c->d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
     const int chunk = pick_chunk(c, n);
     fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n;
     fp.total_items = n * fp.nstrips * fp.nchunks;
@@ -275,10 +294,7 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   c->device = device; c->W = width; c->H = height; c->C = channels; c->max_batch = max_batch; c->mode = mode;
   if (mode == HC_MODE_O) { c->low = 50; c->high = 150; }
   c->nstrips = (width + STRIP_W - 1) / STRIP_W;
-  const int ntiles = (height + 1023) / 1024;
-  const int rows_per = (height + ntiles - 1) / ntiles;
-  c->tile_rows = (int)round_up((size_t)rows_per, 64);
-  c->nrtiles = (height + c->tile_rows - 1) / c->tile_rows;
+  c->RD = (int)round_up(std::max<size_t>((size_t)(width + 31) / 32, ((size_t)c->nstrips * 31 + 3) / 4), 4);
   auto ok = [&](hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     fail(HC_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
@@ -289,9 +305,14 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, (size_t)width * channels, height, max_batch) == HC_OK;
   good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch) == HC_OK;
   if (good && channels == 3) good = alloc_frames(&c->d_mono, &c->mono_pitch, &c->mono_fs, (size_t)width, height, max_batch) == HC_OK;
-  good = good && ok(hipMalloc((void **)&c->d_bm, sizeof(u64) * BM_WORDS * (size_t)height * c->nstrips * max_batch), "hipMalloc(bit planes)");
-  good = good && ok(hipMalloc((void **)&c->d_flags, sizeof(u32) * MAX_HYST_LAUNCHES), "hipMalloc(flags)");
-  good = good && ok(hipHostMalloc((void **)&c->h_flags, sizeof(u32) * MAX_HYST_LAUNCHES, hipHostMallocDefault), "hipHostMalloc(flags)");
+  const size_t plane_bytes = sizeof(u32) * (size_t)c->RD * height * max_batch;
+  good = good && ok(hipMalloc((void **)&c->d_sbits, plane_bytes), "hipMalloc(strong plane)");
+  good = good && ok(hipMalloc((void **)&c->d_cbits, plane_bytes), "hipMalloc(candidate plane)");
+  // row padding beyond the strips' bytes is never written by the kernels and must read as 0
+  good = good && ok(hipMemset(c->d_sbits, 0, plane_bytes), "hipMemset") && ok(hipMemset(c->d_cbits, 0, plane_bytes), "hipMemset");
+  good = good && ok(hipMalloc((void **)&c->d_tflags, (size_t)2 * max_batch * ((height + 7) / 8 + 1)), "hipMalloc(tile flags)");
+  good = good && ok(hipMalloc((void **)&c->d_flags, sizeof(u32) * FLAG_WORDS), "hipMalloc(flags)");
+  good = good && ok(hipHostMalloc((void **)&c->h_flags, sizeof(u32) * FLAG_WORDS, hipHostMallocDefault), "hipHostMalloc(flags)");
   c->evpool.assign((size_t)hc_ctx::EV_RUNS * 4, nullptr);
   for (size_t i = 0; good && i < c->evpool.size(); ++i) good = ok(hipEventCreate(&c->evpool[i]), "hipEventCreate");
   if (good) {
@@ -311,7 +332,7 @@ void hc_destroy(hc_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_bm, (void *)c->d_flags }) (void)hipFree(q);
+  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_sbits, (void *)c->d_cbits, (void *)c->d_tflags, (void *)c->d_flags }) (void)hipFree(q);
   if (c->h_flags) (void)hipHostFree(c->h_flags);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -351,6 +372,7 @@ int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
   if (hyst_launches < 1 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range");
   if (int rc = finish_pending(c)) return rc;
   c->chunk = chunk_rows; c->hyst_launches = hyst_launches;
+  if (const char *e = getenv("HC_HYST_WAVES")) { const int w = atoi(e); if (w == 4 || w == 8 || w == 16) c->hyst_waves = w; }
   return HC_OK;
 }
 
@@ -403,8 +425,8 @@ int hc_hysteresis_device(hc_ctx *c, const void *d_thresh, size_t in_pitch, size_
   HIPCK(hipSetDevice(c->device));
   if (int rc = finish_pending(c)) return rc;
   PackParams pp{};
-  pp.in = (const uint8_t *)d_thresh; pp.in_pitch = in_pitch; pp.in_frame_stride = in_fs; pp.bm = c->d_bm; pp.W = c->W; pp.H = c->H; pp.nstrips = c->nstrips; pp.nframes = n;
-  HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * MAX_HYST_LAUNCHES, c->stream));
+  pp.in = (const uint8_t *)d_thresh; pp.in_pitch = in_pitch; pp.in_frame_stride = in_fs; pp.sbits = c->d_sbits; pp.cbits = c->d_cbits; pp.RD = c->RD; pp.W = c->W; pp.H = c->H; pp.nframes = n;
+  HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * FLAG_WORDS, c->stream));
   HIPCK(launch_pack(pp, c->stream));
   uint8_t *dst = (uint8_t *)d_out;
   size_t dp = out_pitch, dfs = out_fs;
@@ -488,6 +510,14 @@ int hc_device_ptrs(hc_ctx *c, void **d_in, void **d_out, size_t *in_pitch, size_
   if (out_pitch) *out_pitch = c->out_pitch;
   if (in_fs) *in_fs = c->in_fs;
   if (out_fs) *out_fs = c->out_fs;
+  return HC_OK;
+}
+
+int hc_hysteresis_stats(hc_ctx *c, unsigned *stats, int nwords)
+{
+  if (!c || !stats) return fail(HC_E_ARG, "null argument");
+  if (int rc = finish_pending(c)) return rc;
+  for (int i = 0; i < nwords && i < 3 * MAX_HYST_LAUNCHES; ++i) stats[i] = c->h_stats[i];
   return HC_OK;
 }
 

@@ -103,6 +103,10 @@ int hc_device_ptrs(hc_ctx *ctx, void **d_in, void **d_out, size_t *in_pitch, siz
 /* Number of hysteresis launches that did work in the last run, and whether the continuation ran. */
 int hc_last_hysteresis_info(hc_ctx *ctx, int *launches_with_work, int *continued);
 
+/* Diagnostics of the last run's queued hysteresis launches: 3 words per launch
+ * (sweeps summed over tiles, max sweeps of a tile, tiles that did work). */
+int hc_hysteresis_stats(hc_ctx *ctx, unsigned *stats, int nwords);
+
 /* Tuning knobs (rows per fused work item: 0 = auto; hysteresis launches queued per run). */
 int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
 

@@ -128,15 +128,17 @@ def test_hysteresis_device_adversarial(oracle):
         buf[:, :w] = t
         d_in = torch.from_numpy(buf).cuda()
         d_out = torch.zeros((h, pitch), dtype=torch.uint8, device="cuda")
-        with api.Context(w, h, 1, 1) as ctx:
-            ctx.hysteresis_device(d_in.data_ptr(), pitch, pitch * h, d_out.data_ptr(), pitch, pitch * h, 1)
-            ctx.sync()
-            got = d_out.cpu().numpy()[:, :w]
-            _diff(got, want, name)
-            work, cont = ctx.hysteresis_info()
-            assert work >= 1
-            if name.startswith("serpentine_1000"):
-                assert cont == 1  # needs far more cross-tile rounds than the queued launches
+        for launches in (6, 1):
+            with api.Context(w, h, 1, 1) as ctx:
+                ctx.set_tuning(0, launches)
+                ctx.hysteresis_device(d_in.data_ptr(), pitch, pitch * h, d_out.data_ptr(), pitch, pitch * h, 1)
+                ctx.sync()
+                got = d_out.cpu().numpy()[:, :w]
+                _diff(got, want, f"{name} ({launches} queued launches)")
+                work, cont = ctx.hysteresis_info()
+                assert work >= 1
+                if name.startswith("serpentine_1000") and launches == 1:
+                    assert cont == 1  # the path crosses tile boundaries: one queued launch cannot finish it
 
 
 def test_run_device_unaligned_and_torch_stream(oracle):
