@@ -37,6 +37,11 @@ static __device__ __forceinline__ u16x2 U(u32 v) { return __builtin_bit_cast(u16
 static __device__ __forceinline__ i16x2 I(u32 v) { return __builtin_bit_cast(i16x2, v); }
 static __device__ __forceinline__ u32 R(u16x2 v) { return __builtin_bit_cast(u32, v); }
 static __device__ __forceinline__ u32 R(i16x2 v) { return __builtin_bit_cast(u32, v); }
+// single packed-math instructions the compiler would otherwise expand into shift+add pairs, or emit in
+// the accumulate form (v_dot2c) that needs an extra v_mov 0
+static __device__ __forceinline__ u32 pk_mad2(u32 a, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c)); return d; }
+static __device__ __forceinline__ u32 pk_mul5(u32 a) { u32 d; asm("v_pk_mul_lo_u16 %0, %1, 5 op_sel_hi:[1,0]" : "=v"(d) : "v"(a)); return d; }
+static __device__ __forceinline__ int sdot2_0(u32 a, u32 b) { int d; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d; }
 static __device__ __forceinline__ void wave_lds_sync()
 {
   // wave-private LDS hand-off between lanes of ONE wave: DS ops of a wave execute in order, this
@@ -97,15 +102,15 @@ hipError_t launch_selftest(u32 *d_result, hipStream_t s)
 //   phase 1  input rows -> blur rows (u8) into a wave-private LDS slab of CHUNK+4 rows
 //   fix-up   the few pixels whose exact float result cannot be decided by integers (see gauss_row)
 //   phase 2  blur rows -> Sobel -> S = sumX^2+sumY^2 -> direction -> NMS -> thresholds -> bit planes
-constexpr int QCAP = 1024;  // fix-up queue entries (u16) per wave
+constexpr int QCAP = 248;   // fix-up queue entries (u16) per wave (expected fill: 0.6 % of the slab pixels)
 
 template <int CHUNK>
 struct FrontLds {
   static constexpr int BROWS = CHUNK + 4;
-  static constexpr int WAVE_BYTES = BROWS * 256 + QCAP * 2;
+  static constexpr int WAVE_BYTES = BROWS * 256 + QCAP * 2 + 16;
 };
 
-size_t front_lds_bytes(int chunk_rows) { return (size_t)4 * ((chunk_rows + 4) * 256 + QCAP * 2); }
+size_t front_lds_bytes(int chunk_rows) { return (size_t)4 * ((chunk_rows + 4) * 256 + QCAP * 2 + 16); }
 
 // literal reference chain for one pixel (cannyEdgeD.cu:102-115): 25 fused multiply-adds from 0.0f in
 // r-major / c-minor order, truncation.  Only used for the rare undecidable pixels.
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   const int wib = threadIdx.x >> 6;
   unsigned char *blur_s = smem + wib * FrontLds<CHUNK>::WAVE_BYTES;
   unsigned short *queue = reinterpret_cast<unsigned short *>(blur_s + FrontLds<CHUNK>::BROWS * 256);
+  u32 *qcount = reinterpret_cast<u32 *>(queue + QCAP);  // queue fill (may run past QCAP: overflow)
 
   const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
   if (item >= p.total_items) return;
@@ -176,7 +182,8 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   // plus coefficient error) << 1/159, so trunc(chain) == floor(S/159) unless S % 159 == 0; those
   // pixels (0.6 % of random data) are queued and recomputed with the literal fmaf chain.
   u32 a1[2] = { 0, 0 }, a2[2] = { 0, 0 }, a3[2] = { 0, 0 }, a4[2] = { 0, 0 };
-  int qn = 0;  // wave-uniform queue fill
+  if (lane == 0) *qcount = 0;
+  wave_lds_sync();
 
   auto load_row = [&](int row) -> u32 {
     u32 v = 0;
@@ -184,7 +191,6 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
     return v;
   };
 
-  bool overflow = false;  // wave-uniform: more undecidable pixels than the queue holds (flat regions)
 
   auto phase1_row = [&](int jr, u32 xraw) {
     const u32 x = xraw & cmask;
@@ -194,22 +200,24 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
     const u32 p1 = pair_shift(B, A);   // (x1, x2)
     const u32 p3 = pair_shift(Ar, B);  // (x3, x4)
     u32 Sp[2];
+    // NB: every packed u16 sum below stays < 2^16 per half (S <= 40545), so plain 32-bit adds and
+    // subtractions act on both halves at once without carry/borrow between them -- and v_add_u32 /
+    // v_sub_u32 issue at twice the rate of the v_pk_* forms on gfx950 (tools/valu_rate2.hip).
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const u16x2 P = h == 0 ? U(Bl) + U(B) : U(A) + U(Ar);
-      const u16x2 Q = h == 0 ? U(m1) + U(p1) : U(p1) + U(p3);
-      const u16x2 Cc = h == 0 ? U(A) : U(B);
-      const u16x2 two = { 2, 2 }, five = { 5, 5 };
-      const u16x2 e = Q * two + P;
-      const u16x2 h0 = e * two + Cc * five;
-      const u16x2 w = Cc * two + Q;
-      const u16x2 h1 = h0 * two + w;
-      const u16x2 h2 = (h0 + h1) - (P + w);
-      Sp[h] = R(U(a4[h]) + h0);
-      a4[h] = R(U(a3[h]) + h1);
-      a3[h] = R(U(a2[h]) + h2);
-      a2[h] = R(U(a1[h]) + h1);
-      a1[h] = R(h0);
+      const u32 P = h == 0 ? Bl + B : A + Ar;
+      const u32 Q = h == 0 ? m1 + p1 : p1 + p3;
+      const u32 Cc = h == 0 ? A : B;
+      const u32 e = pk_mad2(Q, P);             // 2q + p
+      const u32 h0 = pk_mad2(e, pk_mul5(Cc));  // 2p + 4q + 5c
+      const u32 w = pk_mad2(Cc, Q);            // q + 2c
+      const u32 h1 = pk_mad2(h0, w);           // 4p + 9q + 12c
+      const u32 h2 = (h0 + h1) - (P + w);      // 5p + 12q + 15c
+      Sp[h] = a4[h] + h0;
+      a4[h] = a3[h] + h1;
+      a3[h] = a2[h] + h2;
+      a2[h] = a1[h] + h1;
+      a1[h] = h0;
     }
     const int rb = jr - 2;  // blur row completed by this step
     if (rb >= r0 - 2) {     // wave-uniform
@@ -224,21 +232,18 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
         const u32 n3 = __builtin_amdgcn_udot2(U(Sp[1]), mhi, 0u, false) >> 23;
         const u32 B0 = n0 | (n1 << 16), B1 = n2 | (n3 << 16);
         const u16x2 c159 = { 159, 159 };
-        const u32 rem0 = R(U(Sp[0]) - U(B0) * c159) | inv0, rem1 = R(U(Sp[1]) - U(B1) * c159) | inv1;
+        const u32 rem0 = (Sp[0] - R(U(B0) * c159)) | inv0, rem1 = (Sp[1] - R(U(B1) * c159)) | inv1;  // remainders >= 0: no borrow
         bl = __builtin_amdgcn_perm(B1, B0, 0x06040200u) & cmask;
         // undecidable pixels: remainder 0.  One cheap wave-wide test first.
         const u16x2 z = __builtin_elementwise_min(U(rem0), U(rem1));
-        if (__ballot(z.x == 0 || z.y == 0) != 0) {
-          if (qn + 256 > QCAP) overflow = true;
-        }
-        if (!overflow && __ballot(z.x == 0 || z.y == 0) != 0) {
+        if (z.x == 0 || z.y == 0) {  // few lanes, if any: claim queue slots with an LDS counter
+          u32 fl = ((rem0 & 0xFFFFu) == 0 ? 1u : 0u) | ((rem0 >> 16) == 0 ? 2u : 0u) | ((rem1 & 0xFFFFu) == 0 ? 4u : 0u) | ((rem1 >> 16) == 0 ? 8u : 0u);
           const u32 abase = (u32)slot * 256u + (u32)lane * 4u;
-          const bool f[4] = { (rem0 & 0xFFFFu) == 0, (rem0 >> 16) == 0, (rem1 & 0xFFFFu) == 0, (rem1 >> 16) == 0 };
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const u64 m = __ballot(f[k]);
-            if (f[k]) queue[qn + mbcnt64(m)] = (unsigned short)(abase + k);
-            qn += __builtin_popcountll(m);
+          while (fl) {
+            const u32 k = (u32)__builtin_ctz(fl);
+            fl &= fl - 1;
+            const u32 idx = atomicAdd(qcount, 1u);
+            if (idx < (u32)QCAP) queue[idx] = (unsigned short)(abase + k);
           }
         }
       }
@@ -266,7 +271,8 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   // fix-up: the queued pixels get the literal chain.  If the queue overflowed (large flat regions:
   // every pixel of a constant area has S = 159*v), every pixel of the slab is recomputed instead.
   wave_lds_sync();
-  if (!overflow) {
+  const int qn = (int)__builtin_amdgcn_readfirstlane(*qcount);
+  if (qn <= QCAP) {
 #pragma nounroll
     for (int base = 0; base < qn; base += 64) {
       const int e = base + lane;
@@ -336,25 +342,24 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
       const u32 A = unpack_lo(b), B = unpack_hi(b);
       const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
       const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
-      const i16x2 two = { 2, 2 };
       u32 dk[2], sk[2];
-      dk[0] = R(I(p1) - I(m1));
-      sk[0] = R(I(A) * two + (I(m1) + I(p1)));
+      dk[0] = R(I(p1) - I(m1));      // signed halves: packed op
+      sk[0] = pk_mad2(A, m1 + p1);   // non-negative halves < 2^16: plain add
       dk[1] = R(I(p3) - I(p1));
-      sk[1] = R(I(B) * two + (I(p1) + I(p3)));
+      sk[1] = pk_mad2(B, p1 + p3);
       // Sobel row i = k-1 from blur rows k-2 (ring rn), k-1 (ring rp), k (new)
       const int i = k - 1;
       if (i >= 0 && i < H) {  // wave-uniform
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const u32 pm = h == 0 ? pm0 : pm1;  // sums outside the image are 0 (zero padding of every stage)
-          const u32 X = R(I(dr[rn][h]) + I(dk[h]) + I(dr[rp][h]) * two) & pm;
+          const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;  // two's complement: the u16 mad is exact for i16
           const u32 Y = R(I(sr[rn][h]) - I(sk[h])) & pm;
           Vr[rn][2 * h + 0] = __builtin_amdgcn_perm(Y, X, 0x05040100u);  // (sumX, sumY) of pixel 2h
           Vr[rn][2 * h + 1] = __builtin_amdgcn_perm(Y, X, 0x07060302u);  // pixel 2h+1
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Sr[sN][1 + q] = (u32)__builtin_amdgcn_sdot2(I(Vr[rn][q]), I(Vr[rn][q]), 0, false);
+        for (int q = 0; q < 4; ++q) Sr[sN][1 + q] = (u32)sdot2_0(Vr[rn][q], Vr[rn][q]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) { Sr[sN][1 + q] = 0; Vr[rn][q] = 0; }
@@ -374,17 +379,6 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const u32 g = Sr[sC][1 + q];
-            const u32 V = Vr[rp][q];
-            const i16x2 pm = { 1, -1 };
-            const int D = __builtin_amdgcn_sdot2(I(V), I(V) * pm, 0, false);
-            const int Q = __builtin_amdgcn_sdot2(I(V), I(V >> 16), 0, false);
-            const u64 p1m = __ballot(D - 2 * Q > 0), p2m = __ballot(D + 2 * Q > 0);
-            // neighbours (cannyEdgeD.cu:245-264): bin0 down/up, bin1 down-left/up-right, bin2 right/left, bin3 up-left/down-right
-            const u64 k0 = __ballot(max(Sr[sN][1 + q], Sr[sU][1 + q]) <= g);
-            const u64 k1 = __ballot(max(Sr[sN][q], Sr[sU][2 + q]) <= g);
-            const u64 k2 = __ballot(max(Sr[sC][2 + q], Sr[sC][q]) <= g);
-            const u64 k3 = __ballot(max(Sr[sU][q], Sr[sN][2 + q]) <= g);
-            const u64 keep = (~p1m & ~p2m & k0) | (~p1m & p2m & k1) | (p1m & p2m & k2) | (p1m & ~p2m & k3);
             u64 cl, st;
             if (!wrap) {
               cl = __ballot(g >= a_lo0);
@@ -394,6 +388,18 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
               cl = (__ballot(g >= a_lo0) & ~w0) | (__ballot(g >= p.a_lo[1]) & ~w1) | __ballot(g >= p.a_lo[2]);
               st = (__ballot(g >= a_hi0) & ~w0) | (__ballot(g >= p.a_hi[1]) & ~w1) | __ballot(g >= p.a_hi[2]);
             }
+            if (cl == 0) continue;  // no lane has a candidate in this pixel slot: skip direction + NMS
+            const u32 V = Vr[rp][q];
+            const i16x2 pm = { 1, -1 };
+            const int D = sdot2_0(V, R(I(V) * pm));
+            const int Q = sdot2_0(V, V >> 16);
+            const u64 p1m = __ballot(D - 2 * Q > 0), p2m = __ballot(D + 2 * Q > 0);
+            // neighbours (cannyEdgeD.cu:245-264): bin0 down/up, bin1 down-left/up-right, bin2 right/left, bin3 up-left/down-right
+            const u64 k0 = __ballot(max(Sr[sN][1 + q], Sr[sU][1 + q]) <= g);
+            const u64 k1 = __ballot(max(Sr[sN][q], Sr[sU][2 + q]) <= g);
+            const u64 k2 = __ballot(max(Sr[sC][2 + q], Sr[sC][q]) <= g);
+            const u64 k3 = __ballot(max(Sr[sU][q], Sr[sN][2 + q]) <= g);
+            const u64 keep = (~p1m & ~p2m & k0) | (~p1m & p2m & k1) | (p1m & p2m & k2) | (p1m & ~p2m & k3);
             // per-lane nibbles (bit q = pixel slot q): strong in bits 0..3, candidate in bits 8..11
             nib |= __builtin_amdgcn_inverse_ballot_w64(st & keep) ? (1u << q) : 0u;
             nib |= __builtin_amdgcn_inverse_ballot_w64(cl & keep) ? (0x100u << q) : 0u;
@@ -420,6 +426,7 @@ hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s)
     attr_done = true;
   }
   switch (chunk_rows) {
+    case 8: hipLaunchKernelGGL(k_front<8>, dim3(nblocks), dim3(256), lds, s, p); break;
     case 16: hipLaunchKernelGGL(k_front<16>, dim3(nblocks), dim3(256), lds, s, p); break;
     case 32: hipLaunchKernelGGL(k_front<32>, dim3(nblocks), dim3(256), lds, s, p); break;
     case 64: hipLaunchKernelGGL(k_front<64>, dim3(nblocks), dim3(256), lds, s, p); break;
