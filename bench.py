@@ -23,7 +23,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from cudacam_amd import api, synth  # noqa: E402
+from cudacam_amd import api, shard, synth  # noqa: E402
 
 W, H = 1920, 1080
 LOW, HIGH = 10, 40
@@ -64,6 +64,8 @@ def main():
     dev = torch.device("cuda", local)
 
     B = a.batch
+    f0, f1 = shard.frame_range(B * world, rank, world)   # this rank's block of every step's frame stream
+    assert f1 - f0 == B
     uniq = synth.frames(a.kind, W, H, min(a.unique, B), seed=synth.SEED0 + 1000 * rank)
     d_u = torch.from_numpy(uniq).to(dev)
     reps = (B + d_u.shape[0] - 1) // d_u.shape[0]
@@ -101,11 +103,7 @@ def main():
     sums, nruns = ctx.profile_get(reset=True)
     work_launches, continued = ctx.hysteresis_info()
 
-    elapsed = t1 - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.reduce_max_seconds(t1 - t0, dist if world > 1 else None, dev)
 
     if rank == 0:
         frames_total = B * a.steps * world
@@ -152,7 +150,8 @@ def cpu_baseline(a, d_in, d_out):
     bounded sample of the same frames; the GPU output for that sample is checked against it."""
     from oracle import oracle as O   # test infrastructure: only this leg may touch it
     O.build()
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-core CPU share: size the OpenMP pool to it
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     n = a.cpu_frames or max(cores * 4, 16)
     n = min(n, d_in.shape[0])
     sample = d_in[:n].cpu().numpy()
