@@ -40,6 +40,7 @@ CANNY_STAGES = {
 
 MODE_R, MODE_O = 0, 1
 OPT_NMS_SATURATE = 1
+OPT_PIPELINE = 2
 
 # every symbol include/hipcanny.h declares
 ABI_SYMBOLS = [

@@ -47,6 +47,12 @@ struct HystParams {
   uint8_t *tflags; // [2][nframes][nrtiles]: bit0 first row changed, bit1 last row changed (per launch parity)
   int iter;        // index of this launch
   u32 *stats;      // optional diagnostics (3 words per launch) or null
+  // fused expand: every launch also writes the 0/255 u8 rows it owns (launch 0: all rows of the tile,
+  // later launches: the rows they changed), so no separate bit-plane -> u8 pass is needed
+  uint8_t *out;
+  size_t out_pitch, out_frame_stride;
+  int W;
+  int debug_skip;  // diagnostics: stage and write back only
   int first_pass;  // the planes come straight from k_front / k_pack: rows are not yet closed under the in-row fill
 };
 

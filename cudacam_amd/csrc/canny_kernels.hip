@@ -50,6 +50,11 @@ static __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// tell the compiler a value is wave-uniform (keeps masks and row indices in SGPRs, control flow scalar)
+static __device__ __forceinline__ u64 uniform64(u64 v)
+{
+  return ((u64)(u32)__builtin_amdgcn_readfirstlane((int)(u32)(v >> 32)) << 32) | (u32)__builtin_amdgcn_readfirstlane((int)(u32)v);
+}
 static __device__ __forceinline__ u32 mbcnt64(u64 m) { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); }
 
 // XCD-aware work-item order: blocks are dealt round-robin over the 8 XCDs, so block b and b+8 share
@@ -581,6 +586,13 @@ static __device__ __forceinline__ RowBits<NW> row_dilate(const RowBits<NW> &p)
   return d;
 }
 
+static __device__ __forceinline__ u32 nibble_to_bytes(u32 nib)
+{
+  // bit k -> byte k = 0xFF: (nib * 0x00204081) & 0x01010101 spreads the 4 bits to byte positions
+  const u32 x = (nib * 0x00204081u) & 0x01010101u;
+  return (x << 8) - x;
+}
+
 // Workgroup tile = 4 waves x TR rows (TR <= 64), C rows and S rows (+2 boundary rows owned by the
 // neighbouring workgroups) staged in LDS; each row 64*NW dwords.
 static inline int hyst_nw(int RD) { return RD <= 64 ? 1 : RD <= 128 ? 2 : 4; }
@@ -591,7 +603,7 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
 {
   if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wib = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
   const int bt = blockIdx.x % p.nrtiles, frame = blockIdx.x / p.nrtiles;
   const int H = p.H, RD = p.RD, TR = p.tile_rows, BR = nwaves * TR;
   const int b0 = bt * BR, nb = min(H, b0 + BR) - b0;  // rows of this workgroup tile
@@ -600,8 +612,8 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
   bool top = false, bot = false;
   if (p.iter > 0) {
     // work only if a neighbouring tile changed the row this tile looks at
-    top = bt > 0 && (tf_prev[bt - 1] & 2);
-    bot = bt + 1 < p.nrtiles && (tf_prev[bt + 1] & 1);
+    top = bt > 0 && (__builtin_amdgcn_readfirstlane(tf_prev[bt - 1]) & 2);
+    bot = bt + 1 < p.nrtiles && (__builtin_amdgcn_readfirstlane(tf_prev[bt + 1]) & 1);
     if (!top && !bot) {  // uniform for the workgroup
       if (threadIdx.x == 0) tf_cur[bt] = 0;
       return;
@@ -613,6 +625,7 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
   u64 dirty;  // bit r = row b0 + w0 + r needs (re)evaluation
   if (p.iter > 0) dirty = ((top && w0 == 0 && n > 0) ? 1ull : 0ull) | ((bot && w0 + n == nb && n > 0) ? (1ull << (n - 1)) : 0ull);
   else dirty = all_rows;
+  dirty = uniform64(dirty);
   u64 unfilled = p.first_pass ? all_rows : 0ull;  // rows not yet closed under the in-row fill
 
   constexpr int ROWW = 64 * NW;  // dwords per LDS row
@@ -621,28 +634,39 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
   u32 *bchg = Sl + (size_t)(BR + 2) * ROWW;          // per-wave boundary-change bits of the current round
   u32 *S = p.sbits + (size_t)frame * H * RD;
   const u32 *C = p.cbits + (size_t)frame * H * RD;
-  // stage the tile: rows dealt to the waves round-robin, 8 loads in flight per wave
-  for (int rb = wib * 8; rb < nb + 2; rb += 8 * nwaves) {
-    RowBits<NW> cv[8], sv[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = rb + k - 1;  // -1 .. nb
-      const int gr = b0 + r;
-      const bool inS = r <= nb && gr >= 0 && gr < H, inC = r >= 0 && r < nb;
-#pragma unroll
-      for (int i = 0; i < NW; ++i) { cv[k].w[i] = 0; sv[k].w[i] = 0; }
-      if (inS) sv[k] = row_load<NW>(S + (size_t)gr * RD, lane, RD);
-      if (inC) cv[k] = row_load<NW>(C + (size_t)gr * RD, lane, RD);
+  // Stage the tile with LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, all
+  // in flight at once).  Bit-plane rows are padded to 64*NW dwords, so the rows of a tile are one
+  // contiguous block in HBM and the LDS image is the same bytes.  The two boundary rows of S and
+  // any ragged tail go through registers (rows outside the frame read as 0).
+  {
+    typedef __attribute__((address_space(1))) const void gptr_t;
+    typedef __attribute__((address_space(3))) void lptr_t;
+    constexpr int ROWB = ROWW * 4;          // bytes per row
+    constexpr int RPC = 1024 / ROWB;        // rows per 1 KiB chunk (4, 2 or 1)
+    const int nchunks = nb / RPC;           // whole chunks of interior rows
+    const unsigned char *gC = reinterpret_cast<const unsigned char *>(C + (size_t)b0 * RD);
+    const unsigned char *gS = reinterpret_cast<const unsigned char *>(S + (size_t)b0 * RD);
+    unsigned char *lC = reinterpret_cast<unsigned char *>(Cl), *lS = reinterpret_cast<unsigned char *>(Sl + ROWW);
+    for (int k = wib; k < 2 * nchunks; k += nwaves) {
+      const int ck = k >> 1;
+      if (k & 1) __builtin_amdgcn_global_load_lds((gptr_t *)(gS + (size_t)ck * 1024 + lane * 16), (lptr_t *)(lS + ck * 1024), 16, 0, 0);
+      else __builtin_amdgcn_global_load_lds((gptr_t *)(gC + (size_t)ck * 1024 + lane * 16), (lptr_t *)(lC + ck * 1024), 16, 0, 0);
     }
+    // rows -1, nb (S only) and the tail rows nchunks*RPC .. nb-1 (both planes): one row per wave turn
+    const int tail0 = nchunks * RPC, nextra = (nb - tail0) + 2;
+    for (int e = wib; e < nextra; e += nwaves) {
+      const int r = e == 0 ? -1 : e == 1 ? nb : tail0 + (e - 2);
+      const int gr = b0 + r;
+      RowBits<NW> sv, cv;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int r = rb + k - 1;
-      if (r <= nb)
+      for (int i = 0; i < NW; ++i) sv.w[i] = cv.w[i] = 0;
+      if (gr >= 0 && gr < H) sv = row_load<NW>(S + (size_t)gr * RD, lane, RD);
+      if (r >= 0 && r < nb) cv = row_load<NW>(C + (size_t)gr * RD, lane, RD);
 #pragma unroll
-        for (int i = 0; i < NW; ++i) Sl[(r + 1) * ROWW + lane * NW + i] = sv[k].w[i];
+      for (int i = 0; i < NW; ++i) Sl[(r + 1) * ROWW + lane * NW + i] = sv.w[i];
       if (r >= 0 && r < nb)
 #pragma unroll
-        for (int i = 0; i < NW; ++i) Cl[r * ROWW + lane * NW + i] = cv[k].w[i];
+        for (int i = 0; i < NW; ++i) Cl[r * ROWW + lane * NW + i] = cv.w[i];
     }
   }
   if (threadIdx.x < 32) bchg[threadIdx.x] = 0;
@@ -658,7 +682,7 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
     for (int i = 0; i < NW; ++i) v.w[i] = base[idx * ROWW + lane * NW + i];
     return v;
   };
-  for (int round = 0; round < 4096; ++round) {
+  for (int round = 0; round < (p.debug_skip ? 0 : 4096); ++round) {
     u64 round_changed = 0;
     while (dirty) {
       const int r = __builtin_ctzll(dirty);
@@ -702,11 +726,12 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
       if (wib > 0 && (bchg[wib - 1] & 2u)) dirty |= 1ull;
       if (wib + 1 < nwaves && (bchg[wib + 1] & 1u)) dirty |= 1ull << (n - 1);
     }
+    dirty = uniform64(dirty);
     // workgroup-wide "any wave has work": OR through an LDS word per round parity
     // (no __syncthreads_or: its hidden static LDS would shift the dynamic region)
     if (lane == 0 && dirty != 0) atomicOr(&bchg[18 + (round & 1)], 1u);
     __syncthreads();
-    const bool more = bchg[18 + (round & 1)] != 0;
+    const bool more = __builtin_amdgcn_readfirstlane(bchg[18 + (round & 1)]) != 0;
     if (threadIdx.x == 0) bchg[18 + ((round + 1) & 1)] = 0;
     if (!more) break;
   }
@@ -718,6 +743,32 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
     for (int i = 0; i < NW; ++i) {
       const int dd = lane * NW + i;
       if (dd < RD) S[(size_t)(b0 + w0 + r) * RD + dd] = Sl[(w0 + r + 1) * ROWW + lane * NW + i];
+    }
+  }
+  // fused expand (removeCandidates + output copy, cannyEdgeD.cu:379-395): strong bits -> 255, rest 0.
+  // 16 px per lane per store; launch 0 writes every row of the tile, later launches the changed ones.
+  if (p.out) {
+    const bool a16 = (((uintptr_t)p.out | p.out_pitch | p.out_frame_stride) & 15u) == 0;
+    uint8_t *obase = p.out + (size_t)frame * p.out_frame_stride;
+    for (u64 m = p.iter == 0 ? all_rows : changed; m; m &= m - 1) {
+      const int r = __builtin_ctzll(m);
+      const unsigned short *bits = reinterpret_cast<const unsigned short *>(Sl + (size_t)(w0 + r + 1) * ROWW);
+      uint8_t *orow = obase + (size_t)(b0 + w0 + r) * p.out_pitch;
+      for (int c0 = lane * 16; c0 < p.W; c0 += 1024) {
+        const u32 b = bits[c0 >> 4];
+        u32 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
+        uint8_t *dst = orow + c0;
+        if (c0 + 15 < p.W) {
+          if (a16) *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+          else
+#pragma unroll
+            for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
+        } else {
+          for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+        }
+      }
     }
   }
   const bool first_changed = n > 0 && w0 == 0 && (changed & 1ull);
@@ -770,13 +821,6 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
 // k_expand: strong plane -> u8 edge map (255 / 0); candidates left over are dropped here
 // (removeCandidates, cannyEdgeD.cu:379-395).  16 px per lane: one ushort of bits -> one 16-byte store.
 // =================================================================================================
-static __device__ __forceinline__ u32 nibble_to_bytes(u32 nib)
-{
-  // bit k -> byte k = 0xFF: (nib * 0x00204081) & 0x01010101 spreads the 4 bits to byte positions
-  const u32 x = (nib * 0x00204081u) & 0x01010101u;
-  return (x << 8) - x;
-}
-
 template <bool ALIGN16>
 __global__ __launch_bounds__(256) void k_expand(const ExpandParams p)
 {

@@ -30,13 +30,31 @@ int fail(int code, const std::string &msg)
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr int MAX_HYST_LAUNCHES = 16;
 constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0..15] launch flags, [16..63] 3 diagnostic words per launch
+
+// Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's
+// hysteresis (pipelined mode); the plain mode only uses slot 0.
+struct Slot {
+  u32 *d_sbits = nullptr, *d_cbits = nullptr;  // bit planes [max_batch][H][RD]
+  uint8_t *d_tflags = nullptr;
+  u32 *d_flags = nullptr, *h_flags = nullptr;
+  hipEvent_t ev_front = nullptr, ev_done = nullptr;  // front kernel finished / hysteresis + expand finished
+  bool pending = false;                              // convergence flag not yet checked by the host
+  HystParams ph{};
+  ExpandParams pe{};
+  void *copy_dst = nullptr;  // caller buffer when the expand went to the internal one
+  size_t copy_pitch = 0, copy_fs = 0;
+  int n = 0;
+  hipStream_t stream = nullptr;  // stream the hysteresis of this run was queued on
+};
 }  // namespace
 
 struct hc_ctx {
   int device = 0, W = 0, H = 0, C = 1, max_batch = 1, mode = HC_MODE_R;
   int low = 10, high = 40;
   int nms_saturate = 0;
-  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipStream_t own_stream = nullptr, stream = nullptr;  // context stream (own, or the caller's)
+  hipStream_t s_front = nullptr, s_hyst = nullptr;     // pipelined mode: front kernel / hysteresis + expand
+  hipEvent_t ev_in = nullptr;
   // internal pitched frames
   uint8_t *d_in = nullptr, *d_mono = nullptr, *d_out = nullptr;
   size_t in_pitch = 0, in_fs = 0, mono_pitch = 0, mono_fs = 0, out_pitch = 0, out_fs = 0;
@@ -44,18 +62,11 @@ struct hc_ctx {
   uint8_t *d_blur = nullptr, *d_nms = nullptr;
   int16_t *d_sx = nullptr, *d_sy = nullptr;
   // fused path
-  u32 *d_sbits = nullptr, *d_cbits = nullptr;  // bit planes [max_batch][H][RD]
-  uint8_t *d_tflags = nullptr;
+  Slot slot[2];
+  int cur = 0;
+  bool pipeline = false;
   int RD = 0;
-  u32 *d_flags = nullptr, *h_flags = nullptr;
   int nstrips = 0, chunk = 0, hyst_launches = 6, hyst_waves = 8;
-  // deferred convergence check of the last fused run
-  bool pending = false;
-  HystParams pend_h{};
-  ExpandParams pend_e{};
-  void *pend_copy_dst = nullptr;  // caller buffer when the expand went to the internal one
-  size_t pend_copy_pitch = 0, pend_copy_fs = 0;
-  int pend_n = 0;
   int last_work_launches = 0, last_continued = 0;
   u32 h_stats[3 * 16] = { 0 };
   int uploaded = 0, last_run_n = 0;
@@ -63,8 +74,7 @@ struct hc_ctx {
   // hipEvent ring: 4 events per run (start, after stage 0, after the fused/stage kernels, end)
   static constexpr int EV_RUNS = 256;
   std::vector<hipEvent_t> evpool;
-  int ev_head = 0, ev_count = 0;   // runs recorded since the last collect
-  hipEvent_t *ev = nullptr;        // the 4 events of the run being recorded
+  int ev_head = 0, ev_count = 0;  // runs recorded since the last collect
   float stage_ms[6] = { 0, 0, 0, 0, 0, 0 };
   double prof_sum[3] = { 0, 0, 0 };
   long prof_runs = 0;
@@ -91,6 +101,32 @@ int ensure_stage_scratch(hc_ctx *c)
   return HC_OK;
 }
 
+int alloc_slot(hc_ctx *c, Slot &s)
+{
+  if (s.d_sbits) return HC_OK;
+  const size_t plane_bytes = sizeof(u32) * (size_t)c->RD * c->H * c->max_batch;
+  HIPCK(hipMalloc((void **)&s.d_sbits, plane_bytes));
+  HIPCK(hipMalloc((void **)&s.d_cbits, plane_bytes));
+  // row padding beyond the strips' bytes is never written by the kernels and must read as 0
+  HIPCK(hipMemset(s.d_sbits, 0, plane_bytes));
+  HIPCK(hipMemset(s.d_cbits, 0, plane_bytes));
+  HIPCK(hipMalloc((void **)&s.d_tflags, (size_t)2 * c->max_batch * ((c->H + 7) / 8 + 1)));
+  HIPCK(hipMalloc((void **)&s.d_flags, sizeof(u32) * FLAG_WORDS));
+  HIPCK(hipHostMalloc((void **)&s.h_flags, sizeof(u32) * FLAG_WORDS, hipHostMallocDefault));
+  HIPCK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
+  HIPCK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+  return HC_OK;
+}
+
+void free_slot(Slot &s)
+{
+  for (void *q : { (void *)s.d_sbits, (void *)s.d_cbits, (void *)s.d_tflags, (void *)s.d_flags }) (void)hipFree(q);
+  if (s.h_flags) (void)hipHostFree(s.h_flags);
+  if (s.ev_front) (void)hipEventDestroy(s.ev_front);
+  if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+  s = Slot{};
+}
+
 bool aligned4(const void *p, size_t a, size_t b) { return (((uintptr_t)p | a | b) & 3u) == 0; }
 
 // "stored u8 gradient > T" as thresholds on S = sumX^2+sumY^2 (gradient g = isqrt(S>>2)):
@@ -105,168 +141,192 @@ void band_thresholds(int T, bool saturate, u32 a[3])
   if (saturate && T >= 255) a[0] = 0xFFFFFFFFu;
 }
 
-int pick_chunk(const hc_ctx *c, int nframes)
-{
-  if (c->chunk) return c->chunk;
-  // enough waves to fill 256 CUs x 12 wave slots, otherwise shorter chunks (more waves, more halo work)
-  const long waves32 = (long)nframes * c->nstrips * ((c->H + 31) / 32);
-  return waves32 >= 3072 ? 32 : 16;
-}
-
-int copy_frames_d2d(hc_ctx *c, void *dst, size_t dpitch, size_t dfs, const void *src, size_t spitch, size_t sfs, size_t row_bytes, int n)
+int copy_frames_d2d(hc_ctx *c, hipStream_t st, void *dst, size_t dpitch, size_t dfs, const void *src, size_t spitch, size_t sfs, size_t row_bytes, int n)
 {
   if (dfs == dpitch * (size_t)c->H && sfs == spitch * (size_t)c->H) {
-    HIPCK(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, (size_t)c->H * n, hipMemcpyDeviceToDevice, c->stream));
+    HIPCK(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, (size_t)c->H * n, hipMemcpyDeviceToDevice, st));
   } else {
     for (int f = 0; f < n; ++f)
-      HIPCK(hipMemcpy2DAsync((uint8_t *)dst + dfs * f, dpitch, (const uint8_t *)src + sfs * f, spitch, row_bytes, (size_t)c->H, hipMemcpyDeviceToDevice, c->stream));
+      HIPCK(hipMemcpy2DAsync((uint8_t *)dst + dfs * f, dpitch, (const uint8_t *)src + sfs * f, spitch, row_bytes, (size_t)c->H, hipMemcpyDeviceToDevice, st));
   }
   return HC_OK;
 }
 
-// Finishes the last fused run: if its queued hysteresis launches did not reach the fixpoint
-// (flag of the last one still set -- adversarial inputs only), keep iterating, then redo the expand.
-int finish_pending(hc_ctx *c)
+// Completes a queued fused run: waits for it, and if its queued hysteresis launches did not reach
+// the fixpoint (flag of the last one still set -- adversarial inputs only), keeps iterating, then
+// redoes the expand.
+int finish_slot(hc_ctx *c, Slot &s)
 {
-  if (!c->pending) return HC_OK;
-  c->pending = false;
-  HIPCK(hipStreamSynchronize(c->stream));
+  if (!s.pending) return HC_OK;
+  s.pending = false;
+  hipStream_t st = s.stream;
+  HIPCK(hipEventSynchronize(s.ev_done));
   const int K = c->hyst_launches;
   int work = 0;
-  for (int k = 0; k < K; ++k) work += c->h_flags[k] != 0;
-  std::memcpy(c->h_stats, c->h_flags + MAX_HYST_LAUNCHES, sizeof(c->h_stats));
+  for (int k = 0; k < K; ++k) work += s.h_flags[k] != 0;
+  std::memcpy(c->h_stats, s.h_flags + MAX_HYST_LAUNCHES, sizeof(c->h_stats));
   c->last_work_launches = std::min(K, work + 1);
   c->last_continued = 0;
-  if (c->h_flags[K - 1] == 0) return HC_OK;
+  if (s.h_flags[K - 1] == 0) return HC_OK;
   c->last_continued = 1;
   for (int round = 0; round < 1000000; ++round) {
-    HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * FLAG_WORDS, c->stream));
-    HystParams hp = c->pend_h;
+    HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * FLAG_WORDS, st));
+    HystParams hp = s.ph;
     hp.first_pass = 0;
+    hp.stats = nullptr;
     for (int k = 0; k < K; ++k) {
       hp.iter = k;
-      hp.stats = nullptr;
-      HIPCK(launch_hyst(hp, c->stream));
+      HIPCK(launch_hyst(hp, st));
     }
-    HIPCK(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, c->stream));
-    HIPCK(hipStreamSynchronize(c->stream));
-    for (int k = 0; k < K; ++k) c->last_work_launches += c->h_flags[k] != 0;
-    if (c->h_flags[K - 1] == 0) break;
+    HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, st));
+    HIPCK(hipStreamSynchronize(st));
+    for (int k = 0; k < K; ++k) c->last_work_launches += s.h_flags[k] != 0;
+    if (s.h_flags[K - 1] == 0) break;
   }
-  HIPCK(launch_expand(c->pend_e, c->stream));
-  if (c->pend_copy_dst)
-    if (int rc = copy_frames_d2d(c, c->pend_copy_dst, c->pend_copy_pitch, c->pend_copy_fs, c->pend_e.out, c->pend_e.out_pitch, c->pend_e.out_frame_stride, (size_t)c->W, c->pend_n)) return rc;
-  HIPCK(hipStreamSynchronize(c->stream));
+  if (s.copy_dst)
+    if (int rc = copy_frames_d2d(c, st, s.copy_dst, s.copy_pitch, s.copy_fs, s.pe.out, s.pe.out_pitch, s.pe.out_frame_stride, (size_t)c->W, s.n)) return rc;
+  HIPCK(hipStreamSynchronize(st));
   return HC_OK;
 }
 
-// bit planes -> fixpoint -> u8 image
-int run_hyst_expand(hc_ctx *c, uint8_t *out, size_t out_pitch, size_t out_fs, int n)
+int finish_all(hc_ctx *c)
+{
+  // oldest first
+  if (int rc = finish_slot(c, c->slot[c->cur])) return rc;
+  return finish_slot(c, c->slot[c->cur ^ 1]);
+}
+
+// bit planes of slot s -> fixpoint -> u8 image, queued on `st`
+int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t out_pitch, size_t out_fs, int n, bool small_tiles)
 {
   const int K = c->hyst_launches;
   HystParams hp{};
-  hp.sbits = c->d_sbits; hp.cbits = c->d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = c->d_flags; hp.tflags = c->d_tflags;
-  // one workgroup per (frame, tile of `waves` x tile_rows rows) staged in LDS (<= 150 KB)
+  hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags; hp.tflags = s.d_tflags;
+  // one workgroup per (frame, tile of `waves` x tile_rows rows) staged in LDS
   {
-    int br = 256;  // rows per workgroup tile
-    while (br > 32 && hyst_lds_bytes(c->RD, br) > 150 * 1024) br /= 2;
+    if (const char *e = getenv("HC_HYST_ROWS")) small_tiles = atoi(e) <= 128;
+    int br = small_tiles ? 128 : 256;  // rows per workgroup tile (128: leaves LDS for co-resident front-kernel workgroups)
+    const size_t cap = small_tiles ? 72 * 1024 : 150 * 1024;
+    while (br > 32 && hyst_lds_bytes(c->RD, br) > cap) br /= 2;
     while (br > 32 && br / 2 >= c->H) br /= 2;  // small frames: do not stage empty rows
-    hp.waves = c->hyst_waves;
+    hp.waves = std::min(c->hyst_waves, br / 8);
     hp.tile_rows = br / hp.waves;
     hp.nrtiles = (c->H + br - 1) / br;
   }
+  hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
+  hp.debug_skip = getenv("HC_DEBUG_SKIP_HYST") ? 1 : 0;
   for (int k = 0; k < K; ++k) {
     hp.iter = k;
-    hp.stats = c->d_flags + MAX_HYST_LAUNCHES + 3 * k;
-    HIPCK(launch_hyst(hp, c->stream));
+    // diagnostics cost ~3 same-address atomics per wave (hundreds of microseconds per launch): opt-in only
+    hp.stats = getenv("HC_HYST_DIAG") ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
+    HIPCK(launch_hyst(hp, st));
   }
-  ExpandParams ep{};
-  ep.sbits = c->d_sbits; ep.RD = c->RD; ep.out = out; ep.out_pitch = out_pitch; ep.out_frame_stride = out_fs; ep.W = c->W; ep.H = c->H; ep.nframes = n;
-  HIPCK(launch_expand(ep, c->stream));
-  HIPCK(hipMemcpyAsync(c->h_flags, c->d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, c->stream));
-  c->pending = true;
-  c->pend_h = hp;
-  c->pend_e = ep;
-  c->pend_n = n;
+  ExpandParams ep{};  // (kept for the copy-out bookkeeping; the expand itself is fused into k_hyst)
+  ep.sbits = s.d_sbits; ep.RD = c->RD; ep.out = out; ep.out_pitch = out_pitch; ep.out_frame_stride = out_fs; ep.W = c->W; ep.H = c->H; ep.nframes = n;
+  HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, st));
+  s.pending = true;
+  s.ph = hp;
+  s.pe = ep;
+  s.n = n;
+  s.stream = st;
+  s.copy_dst = nullptr;
   return HC_OK;
 }
 
 int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_t *out, size_t out_pitch, size_t out_fs, int n, int stage)
 {
-  if (int rc = finish_pending(c)) return rc;
   if (c->mode != HC_MODE_R) return fail(HC_E_ARG, "mode O is not built into this library version");
   const int W = c->W, H = c->H;
+  const bool piped = c->pipeline && stage == HC_STAGE_HYSTER;
+  Slot &s = c->slot[piped ? c->cur : 0];
+  if (piped) {
+    if (int rc = alloc_slot(c, s)) return rc;
+    if (int rc = finish_slot(c, s)) return rc;  // the run that used this slot two steps ago
+  } else if (int rc = finish_all(c)) return rc;
+  // streams: plain mode = everything on the context stream; pipelined = front on s_front, rest on s_hyst
+  hipStream_t sf = piped ? c->s_front : c->stream, sh = piped ? c->s_hyst : c->stream;
+  if (piped) {  // the front kernel must see the caller's earlier work on the context stream
+    HIPCK(hipEventRecord(c->ev_in, c->stream));
+    HIPCK(hipStreamWaitEvent(sf, c->ev_in, 0));
+  }
   // unaligned caller buffers go through the internal pitched ones
   const uint8_t *src = in;
   size_t sp = in_pitch, sfs = in_fs;
   if (!aligned4(in, in_pitch, in_fs)) {
-    if (int rc = copy_frames_d2d(c, c->d_in, c->in_pitch, c->in_fs, in, in_pitch, in_fs, (size_t)W * c->C, n)) return rc;
+    if (int rc = copy_frames_d2d(c, sf, c->d_in, c->in_pitch, c->in_fs, in, in_pitch, in_fs, (size_t)W * c->C, n)) return rc;
     src = c->d_in; sp = c->in_pitch; sfs = c->in_fs;
   }
   uint8_t *dst = out;
   size_t dp = out_pitch, dfs = out_fs;
   const bool out_internal = !aligned4(out, out_pitch, out_fs);
   if (out_internal) { dst = c->d_out; dp = c->out_pitch; dfs = c->out_fs; }
-  c->pend_copy_dst = nullptr;
 
   const bool prof = c->profiling && c->ev_count < hc_ctx::EV_RUNS;  // ring full: this run goes untimed
+  hipEvent_t *ev = nullptr;
   if (prof) {
-    c->ev = &c->evpool[(size_t)((c->ev_head + c->ev_count) % hc_ctx::EV_RUNS) * 4];
-    HIPCK(hipEventRecord(c->ev[0], c->stream));
+    ev = &c->evpool[(size_t)((c->ev_head + c->ev_count) % hc_ctx::EV_RUNS) * 4];
+    HIPCK(hipEventRecord(ev[0], sf));
   }
   // stage 0 (cannyEdgeH.cu:214-227); 1-channel input skips it (the reference's mono path is broken, SURVEY §3 ii)
   const uint8_t *mono = src;
   size_t mp = sp, mfs = sfs;
   if (c->C == 3) {
     if (stage == HC_STAGE_MONO) {
-      HIPCK(launch_gray(src, sp, sfs, dst, dp, dfs, W, H, n, c->stream));
+      HIPCK(launch_gray(src, sp, sfs, dst, dp, dfs, W, H, n, sf));
     } else {
-      HIPCK(launch_gray(src, sp, sfs, c->d_mono, c->mono_pitch, c->mono_fs, W, H, n, c->stream));
+      HIPCK(launch_gray(src, sp, sfs, c->d_mono, c->mono_pitch, c->mono_fs, W, H, n, sf));
       mono = c->d_mono; mp = c->mono_pitch; mfs = c->mono_fs;
     }
   } else if (stage == HC_STAGE_MONO) {
-    if (int rc = copy_frames_d2d(c, dst, dp, dfs, src, sp, sfs, (size_t)W, n)) return rc;
+    if (int rc = copy_frames_d2d(c, sf, dst, dp, dfs, src, sp, sfs, (size_t)W, n)) return rc;
   }
-  if (stage == HC_STAGE_HYSTER) HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * FLAG_WORDS, c->stream));
-  if (prof) HIPCK(hipEventRecord(c->ev[1], c->stream));
+  if (prof) HIPCK(hipEventRecord(ev[1], sf));
 
   if (stage == HC_STAGE_HYSTER) {
     FrontParams fp{};
-    fp.in = mono; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = c->d_sbits; fp.cbits = c->d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
-    const int chunk = pick_chunk(c, n);
+    fp.in = mono; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = s.d_sbits; fp.cbits = s.d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
+    const int chunk = c->chunk ? c->chunk : 16;
     fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n;
     fp.total_items = n * fp.nstrips * fp.nchunks;
     band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);
     band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
     fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
-    HIPCK(launch_front(fp, chunk, c->stream));
-    if (prof) HIPCK(hipEventRecord(c->ev[2], c->stream));
-    if (int rc = run_hyst_expand(c, dst, dp, dfs, n)) return rc;
+    HIPCK(launch_front(fp, chunk, sf));
+    if (prof) HIPCK(hipEventRecord(ev[2], sf));
+    if (piped) {
+      HIPCK(hipEventRecord(s.ev_front, sf));
+      HIPCK(hipStreamWaitEvent(c->stream, s.ev_front, 0));  // the caller may now overwrite the input
+      HIPCK(hipStreamWaitEvent(sh, s.ev_front, 0));
+    }
+    HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * FLAG_WORDS, sh));
+    if (int rc = queue_hyst_expand(c, s, sh, dst, dp, dfs, n, piped && !getenv("HC_PIPE_BIG_TILES"))) return rc;
   } else if (stage > HC_STAGE_MONO) {
     if (int rc = ensure_stage_scratch(c)) return rc;
     const size_t bp = c->out_pitch, bfs = c->out_fs;  // scratch planes share the output geometry
     uint8_t *blur = stage == HC_STAGE_GAUSSIAN ? dst : c->d_blur;
     const size_t blp = stage == HC_STAGE_GAUSSIAN ? dp : bp, blfs = stage == HC_STAGE_GAUSSIAN ? dfs : bfs;
-    HIPCK(launch_gauss(mono, mp, mfs, blur, blp, blfs, W, H, n, c->stream));
+    HIPCK(launch_gauss(mono, mp, mfs, blur, blp, blfs, W, H, n, sf));
     if (stage >= HC_STAGE_GRADIENT) {
-      HIPCK(launch_sobel(blur, blp, blfs, c->d_sx, c->d_sy, bp, bfs, W, H, n, c->stream));
-      if (stage == HC_STAGE_GRADIENT) HIPCK(launch_graddisp(c->d_sx, c->d_sy, bp, bfs, dst, dp, dfs, W, H, n, c->stream));
+      HIPCK(launch_sobel(blur, blp, blfs, c->d_sx, c->d_sy, bp, bfs, W, H, n, sf));
+      if (stage == HC_STAGE_GRADIENT) HIPCK(launch_graddisp(c->d_sx, c->d_sy, bp, bfs, dst, dp, dfs, W, H, n, sf));
       else {
         uint8_t *nms = stage == HC_STAGE_NMS ? dst : c->d_nms;
         const size_t np = stage == HC_STAGE_NMS ? dp : bp, nfs = stage == HC_STAGE_NMS ? dfs : bfs;
-        HIPCK(launch_nms(c->d_sx, c->d_sy, bp, bfs, nms, np, nfs, W, H, n, c->nms_saturate, c->stream));
-        if (stage == HC_STAGE_THRESH) HIPCK(launch_thresh(nms, np, nfs, dst, dp, dfs, W, H, n, c->low, c->high, c->stream));
+        HIPCK(launch_nms(c->d_sx, c->d_sy, bp, bfs, nms, np, nfs, W, H, n, c->nms_saturate, sf));
+        if (stage == HC_STAGE_THRESH) HIPCK(launch_thresh(nms, np, nfs, dst, dp, dfs, W, H, n, c->low, c->high, sf));
       }
     }
-    if (prof) HIPCK(hipEventRecord(c->ev[2], c->stream));
-  } else if (prof) HIPCK(hipEventRecord(c->ev[2], c->stream));
-  if (prof) { HIPCK(hipEventRecord(c->ev[3], c->stream)); c->ev_count++; }
+    if (prof) HIPCK(hipEventRecord(ev[2], sf));
+  } else if (prof) HIPCK(hipEventRecord(ev[2], sf));
 
   if (out_internal) {
-    if (int rc = copy_frames_d2d(c, out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)W, n)) return rc;
-    if (c->pending) { c->pend_copy_dst = out; c->pend_copy_pitch = out_pitch; c->pend_copy_fs = out_fs; }
+    if (int rc = copy_frames_d2d(c, sh, out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)W, n)) return rc;
+    if (s.pending) { s.copy_dst = out; s.copy_pitch = out_pitch; s.copy_fs = out_fs; }
   }
+  if (prof) { HIPCK(hipEventRecord(ev[3], sh)); c->ev_count++; }
+  if (stage == HC_STAGE_HYSTER) HIPCK(hipEventRecord(s.ev_done, sh));
+  if (piped) c->cur ^= 1;
   c->last_run_n = n;
   return HC_OK;
 }
@@ -276,7 +336,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
 extern "C" {
 
 const char *hc_last_error(void) { return g_err.c_str(); }
-const char *hc_version(void) { return "hipcanny 0.1 (gfx950)"; }
+const char *hc_version(void) { return "hipcanny 0.2 (gfx950)"; }
 
 hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch, int mode)
 {
@@ -294,25 +354,26 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   c->device = device; c->W = width; c->H = height; c->C = channels; c->max_batch = max_batch; c->mode = mode;
   if (mode == HC_MODE_O) { c->low = 50; c->high = 150; }
   c->nstrips = (width + STRIP_W - 1) / STRIP_W;
-  c->RD = (int)round_up(std::max<size_t>((size_t)(width + 31) / 32, ((size_t)c->nstrips * 31 + 3) / 4), 4);
+  // bit-plane row: covers every strip's 31 bytes, padded to a multiple of 64 dwords (one LDS row per wave)
+  {
+    const size_t need = std::max<size_t>((size_t)(width + 31) / 32, ((size_t)c->nstrips * 31 + 3) / 4);
+    if (need > 256) { fail(HC_E_ARG, "hc_create: width above 8192 is not supported"); delete c; return nullptr; }
+    c->RD = need <= 64 ? 64 : need <= 128 ? 128 : 256;  // 64 * NW dwords, NW in {1, 2, 4}
+  }
   auto ok = [&](hipError_t e, const char *what) {
     if (e == hipSuccess) return true;
     fail(HC_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
     return false;
   };
   bool good = ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
+  good = good && ok(hipStreamCreateWithFlags(&c->s_front, hipStreamNonBlocking), "hipStreamCreate");
+  good = good && ok(hipStreamCreateWithFlags(&c->s_hyst, hipStreamNonBlocking), "hipStreamCreate");
+  good = good && ok(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming), "hipEventCreate");
   c->stream = c->own_stream;
   good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, (size_t)width * channels, height, max_batch) == HC_OK;
   good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch) == HC_OK;
   if (good && channels == 3) good = alloc_frames(&c->d_mono, &c->mono_pitch, &c->mono_fs, (size_t)width, height, max_batch) == HC_OK;
-  const size_t plane_bytes = sizeof(u32) * (size_t)c->RD * height * max_batch;
-  good = good && ok(hipMalloc((void **)&c->d_sbits, plane_bytes), "hipMalloc(strong plane)");
-  good = good && ok(hipMalloc((void **)&c->d_cbits, plane_bytes), "hipMalloc(candidate plane)");
-  // row padding beyond the strips' bytes is never written by the kernels and must read as 0
-  good = good && ok(hipMemset(c->d_sbits, 0, plane_bytes), "hipMemset") && ok(hipMemset(c->d_cbits, 0, plane_bytes), "hipMemset");
-  good = good && ok(hipMalloc((void **)&c->d_tflags, (size_t)2 * max_batch * ((height + 7) / 8 + 1)), "hipMalloc(tile flags)");
-  good = good && ok(hipMalloc((void **)&c->d_flags, sizeof(u32) * FLAG_WORDS), "hipMalloc(flags)");
-  good = good && ok(hipHostMalloc((void **)&c->h_flags, sizeof(u32) * FLAG_WORDS, hipHostMallocDefault), "hipHostMalloc(flags)");
+  good = good && alloc_slot(c, c->slot[0]) == HC_OK;
   c->evpool.assign((size_t)hc_ctx::EV_RUNS * 4, nullptr);
   for (size_t i = 0; good && i < c->evpool.size(); ++i) good = ok(hipEventCreate(&c->evpool[i]), "hipEventCreate");
   if (good) {
@@ -323,6 +384,7 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     for (int i = 0; i < 25; ++i) { volatile float k = (float)K[i]; volatile float v = k * r; gk[i] = v; }
     good = ok(upload_gauss_coeffs(gk), "hipMemcpyToSymbol(GK)");
   }
+  if (const char *e = getenv("HC_HYST_WAVES")) { const int w = atoi(e); if (w == 4 || w == 8 || w == 16) c->hyst_waves = w; }
   if (!good) { hc_destroy(c); return nullptr; }
   return c;
 }
@@ -331,11 +393,13 @@ void hc_destroy(hc_ctx *c)
 {
   if (!c) return;
   (void)hipSetDevice(c->device);
-  if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
-  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_sbits, (void *)c->d_cbits, (void *)c->d_tflags, (void *)c->d_flags }) (void)hipFree(q);
-  if (c->h_flags) (void)hipHostFree(c->h_flags);
+  (void)hipDeviceSynchronize();
+  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy }) (void)hipFree(q);
+  free_slot(c->slot[0]);
+  free_slot(c->slot[1]);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
-  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  for (hipStream_t st : { c->own_stream, c->s_front, c->s_hyst }) if (st) (void)hipStreamDestroy(st);
   delete c;
 }
 
@@ -360,7 +424,7 @@ int hc_get_thresholds(const hc_ctx *c, int *low, int *high)
 int hc_set_stream(hc_ctx *c, void *s)
 {
   if (!c) return fail(HC_E_ARG, "null context");
-  if (int rc = finish_pending(c)) return rc;
+  if (int rc = finish_all(c)) return rc;
   c->stream = s ? (hipStream_t)s : c->own_stream;
   return HC_OK;
 }
@@ -370,18 +434,22 @@ int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
   if (!c) return fail(HC_E_ARG, "null context");
   if (chunk_rows != 0 && chunk_rows != 8 && chunk_rows != 16 && chunk_rows != 32 && chunk_rows != 64) return fail(HC_E_ARG, "chunk_rows must be 0, 8, 16, 32 or 64");
   if (hyst_launches < 1 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range");
-  if (int rc = finish_pending(c)) return rc;
+  if (int rc = finish_all(c)) return rc;
   c->chunk = chunk_rows; c->hyst_launches = hyst_launches;
-  if (const char *e = getenv("HC_HYST_WAVES")) { const int w = atoi(e); if (w == 4 || w == 8 || w == 16) c->hyst_waves = w; }
   return HC_OK;
 }
 
 int hc_set_option(hc_ctx *c, int option, int value)
 {
   if (!c) return fail(HC_E_ARG, "null context");
-  if (option != HC_OPT_NMS_SATURATE) return fail(HC_E_ARG, "hc_set_option: unknown option");
-  if (int rc = finish_pending(c)) return rc;
-  c->nms_saturate = value != 0;
+  if (int rc = finish_all(c)) return rc;
+  if (option == HC_OPT_NMS_SATURATE) c->nms_saturate = value != 0;
+  else if (option == HC_OPT_PIPELINE) {
+    HIPCK(hipSetDevice(c->device));
+    if (value && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;
+    c->pipeline = value != 0;
+    c->cur = 0;
+  } else return fail(HC_E_ARG, "hc_set_option: unknown option");
   return HC_OK;
 }
 
@@ -391,8 +459,8 @@ int hc_upload(hc_ctx *c, const uint8_t *host, size_t row_stride, size_t frame_st
   if (n <= 0 || n > c->max_batch) return fail(HC_E_ARG, "hc_upload: nframes out of range");
   const size_t rb = (size_t)c->W * c->C;
   if (row_stride < rb) return fail(HC_E_ARG, "hc_upload: row_stride smaller than a row");
-  if (int rc = finish_pending(c)) return rc;
   HIPCK(hipSetDevice(c->device));
+  if (int rc = finish_all(c)) return rc;
   for (int f = 0; f < n; ++f)  // cannyEdgeH.cu:136/144 (cudaMemcpy2D host -> pitched device)
     HIPCK(hipMemcpy2DAsync(c->d_in + c->in_fs * f, c->in_pitch, host + frame_stride * f, row_stride, rb, (size_t)c->H, hipMemcpyHostToDevice, c->stream));
   c->uploaded = n;
@@ -423,21 +491,22 @@ int hc_hysteresis_device(hc_ctx *c, const void *d_thresh, size_t in_pitch, size_
   if (!c || !d_thresh || !d_out) return fail(HC_E_ARG, "hc_hysteresis_device: null argument");
   if (n <= 0 || n > c->max_batch) return fail(HC_E_ARG, "hc_hysteresis_device: nframes out of range");
   HIPCK(hipSetDevice(c->device));
-  if (int rc = finish_pending(c)) return rc;
+  if (int rc = finish_all(c)) return rc;
+  Slot &s = c->slot[0];
   PackParams pp{};
-  pp.in = (const uint8_t *)d_thresh; pp.in_pitch = in_pitch; pp.in_frame_stride = in_fs; pp.sbits = c->d_sbits; pp.cbits = c->d_cbits; pp.RD = c->RD; pp.W = c->W; pp.H = c->H; pp.nframes = n;
-  HIPCK(hipMemsetAsync(c->d_flags, 0, sizeof(u32) * FLAG_WORDS, c->stream));
+  pp.in = (const uint8_t *)d_thresh; pp.in_pitch = in_pitch; pp.in_frame_stride = in_fs; pp.sbits = s.d_sbits; pp.cbits = s.d_cbits; pp.RD = c->RD; pp.W = c->W; pp.H = c->H; pp.nframes = n;
+  HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * FLAG_WORDS, c->stream));
   HIPCK(launch_pack(pp, c->stream));
   uint8_t *dst = (uint8_t *)d_out;
   size_t dp = out_pitch, dfs = out_fs;
   const bool out_internal = !aligned4(d_out, out_pitch, out_fs);
   if (out_internal) { dst = c->d_out; dp = c->out_pitch; dfs = c->out_fs; }
-  c->pend_copy_dst = nullptr;
-  if (int rc = run_hyst_expand(c, dst, dp, dfs, n)) return rc;
+  if (int rc = queue_hyst_expand(c, s, c->stream, dst, dp, dfs, n, false)) return rc;
   if (out_internal) {
-    if (int rc = copy_frames_d2d(c, d_out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)c->W, n)) return rc;
-    c->pend_copy_dst = d_out; c->pend_copy_pitch = out_pitch; c->pend_copy_fs = out_fs;
+    if (int rc = copy_frames_d2d(c, c->stream, d_out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)c->W, n)) return rc;
+    s.copy_dst = d_out; s.copy_pitch = out_pitch; s.copy_fs = out_fs;
   }
+  HIPCK(hipEventRecord(s.ev_done, c->stream));
   return HC_OK;
 }
 
@@ -445,7 +514,9 @@ int hc_sync(hc_ctx *c)
 {
   if (!c) return fail(HC_E_ARG, "null context");
   HIPCK(hipSetDevice(c->device));
-  if (int rc = finish_pending(c)) return rc;
+  if (int rc = finish_all(c)) return rc;
+  HIPCK(hipStreamSynchronize(c->s_front));
+  HIPCK(hipStreamSynchronize(c->s_hyst));
   HIPCK(hipStreamSynchronize(c->stream));
   while (c->ev_count > 0) {  // collect the event pairs of every run recorded since the last sync
     hipEvent_t *e = &c->evpool[(size_t)c->ev_head * 4];
@@ -516,7 +587,7 @@ int hc_device_ptrs(hc_ctx *c, void **d_in, void **d_out, size_t *in_pitch, size_
 int hc_hysteresis_stats(hc_ctx *c, unsigned *stats, int nwords)
 {
   if (!c || !stats) return fail(HC_E_ARG, "null argument");
-  if (int rc = finish_pending(c)) return rc;
+  if (int rc = finish_all(c)) return rc;
   for (int i = 0; i < nwords && i < 3 * MAX_HYST_LAUNCHES; ++i) stats[i] = c->h_stats[i];
   return HC_OK;
 }
@@ -524,7 +595,7 @@ int hc_hysteresis_stats(hc_ctx *c, unsigned *stats, int nwords)
 int hc_last_hysteresis_info(hc_ctx *c, int *launches_with_work, int *continued)
 {
   if (!c) return fail(HC_E_ARG, "null context");
-  if (int rc = finish_pending(c)) return rc;
+  if (int rc = finish_all(c)) return rc;
   if (launches_with_work) *launches_with_work = c->last_work_launches;
   if (continued) *continued = c->last_continued;
   return HC_OK;

@@ -113,8 +113,14 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
 /* Options.  HC_OPT_NMS_SATURATE (default 0): the reference stores `min((unsigned char)gradVal, 255)`
  * (src/cvp/cannyEdgeD.cu:267), an out-of-range float->u8 cast for gradients 256..721.  0 = the
  * canonical Mode R reading: the value wraps mod 256 (integer min folds away, low byte stored).
- * 1 = min(g, 255): what the same source line yields when compiled by hipcc for gfx950. */
-enum { HC_OPT_NMS_SATURATE = 1 };
+ * 1 = min(g, 255): what the same source line yields when compiled by hipcc for gfx950.
+ *
+ * HC_OPT_PIPELINE (default 0): throughput mode for back-to-back batches.  1 = the front kernel of
+ * run i+1 (own stream) overlaps the hysteresis + expand of run i (second stream, second set of bit
+ * planes).  The context stream still orders each run after the caller's earlier work and is held
+ * until the run's input has been consumed; the OUTPUT of a run is only guaranteed after hc_sync()
+ * (or hc_download).  Results are identical in both modes. */
+enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* Device self-test of the cross-lane / packed-math primitives the kernels rely on. 0 = ok. */

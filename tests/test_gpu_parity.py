@@ -154,6 +154,32 @@ def test_run_device_unaligned_and_torch_stream(oracle):
         _diff(d_out.cpu().numpy(), want, "unaligned run_device")
 
 
+def test_pipelined_runs(oracle):
+    """HC_OPT_PIPELINE: back-to-back device runs overlap (front of run i+1 / hysteresis of run i);
+    every run's output must still be exactly the oracle's after hc_sync."""
+    import torch
+    w, h, nb = 500, 300, 3
+    batches = [np.stack([synth.natural(w, h, 40 + 10 * r + f) for f in range(nb)]) for r in range(5)]
+    want = [oracle.canny_r_batch(b, 10, 40, threads=4) for b in batches]
+    d_in = [torch.from_numpy(b).cuda() for b in batches]
+    d_out = [torch.zeros_like(t) for t in d_in]
+    with api.Context(w, h, 1, nb) as ctx:
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        for rep in range(2):
+            for r in range(5):
+                ctx.run_device(d_in[r].data_ptr(), w, w * h, d_out[r].data_ptr(), w, w * h, nb)
+            ctx.sync()
+            for r in range(5):
+                got = d_out[r].cpu().numpy()
+                for f in range(nb):
+                    _diff(got[f], want[r][f], f"pipelined rep {rep} run {r} frame {f}")
+                d_out[r].zero_()
+        ctx.set_option(api.OPT_PIPELINE, 0)
+        ctx.run_device(d_in[0].data_ptr(), w, w * h, d_out[0].data_ptr(), w, w * h, nb)
+        ctx.sync()
+        _diff(d_out[0].cpu().numpy()[1], want[0][1], "plain mode after pipelined mode")
+
+
 def test_python_mirror_of_reference_operator(oracle):
     img = synth.natural(320, 200, 31)
     pipe = api.cvPipeline(0, 320, 200, 1)

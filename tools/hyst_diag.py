@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostics: sweeps / active tiles per hysteresis launch on the bench workload."""
 import sys, os, time
+os.environ['HC_HYST_DIAG'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cudacam_amd import api, synth
 api.preload_hip_runtime()
