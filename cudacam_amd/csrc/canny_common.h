@@ -79,7 +79,7 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 hipError_t launch_expand(const ExpandParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
 size_t front_lds_bytes(int chunk_rows);
-size_t hyst_lds_bytes(int RD, int block_rows);
+void hyst_tile_geometry(int RD, int *tile_rows, int *waves);
 
 // plain per-stage kernels (exact, unfused): the `finalStage` taps MONO..THRESH of CannyEdge::run
 hipError_t launch_gray(const uint8_t *bgr, size_t bpitch, size_t bfs, uint8_t *mono, size_t mpitch, size_t mfs, int W, int H, int n, hipStream_t s);

@@ -14,6 +14,8 @@
 // >= 256 and the non-strict NMS.
 #include "canny_common.h"
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 namespace hc {
 
@@ -593,19 +595,41 @@ static __device__ __forceinline__ u32 nibble_to_bytes(u32 nib)
   return (x << 8) - x;
 }
 
-// Workgroup tile = 4 waves x TR rows (TR <= 64), C rows and S rows (+2 boundary rows owned by the
-// neighbouring workgroups) staged in LDS; each row 64*NW dwords.
-static inline int hyst_nw(int RD) { return RD <= 64 ? 1 : RD <= 128 ? 2 : 4; }
-size_t hyst_lds_bytes(int RD, int block_rows) { return (size_t)(2 * block_rows + 2) * 64 * hyst_nw(RD) * 4 + 128; }
+// Workgroup tile = WAVES waves x TR rows.  Every wave keeps its TR rows of both planes in REGISTERS
+// (lane l holds dwords l*NW.. of each row; rows are picked with a wave-uniform index, which the
+// compiler turns into VGPR-indexed moves); LDS only carries the rows neighbours look at.
+struct HystGeom { int nw, tr, waves; };
+static inline HystGeom hyst_geom(int RD)
+{
+  if (RD <= 64) {
+    if (const char *e = getenv("HC_HYST_GEOM")) {  // tuning experiments: "32x4", "16x8", "32x16"
+      if (!strcmp(e, "32x4")) return { 1, 32, 4 };
+      if (!strcmp(e, "16x8")) return { 1, 16, 8 };
+      if (!strcmp(e, "32x16")) return { 1, 32, 16 };
+    }
+    return { 1, 32, 8 };  // 256 rows per workgroup
+  }
+  if (RD <= 128) return { 2, 32, 8 };   // 256 rows
+  return { 4, 16, 8 };                  // 128 rows
+}
+void hyst_tile_geometry(int RD, int *tile_rows, int *waves)
+{
+  const HystGeom g = hyst_geom(RD);
+  *tile_rows = g.tr;
+  *waves = g.waves;
+}
 
-template <int NW>
-__global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
+template <int NW, int TR, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 {
   if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwaves = blockDim.x >> 6;
+  constexpr int ROWW = 64 * NW;  // dwords per row
+  constexpr int BR = WAVES * TR;
+  __shared__ u32 edge[(2 * WAVES + 2) * ROWW];  // per wave: first and last row of S; then the two halo rows
+  __shared__ u32 bchg[24];
+  const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int bt = blockIdx.x % p.nrtiles, frame = blockIdx.x / p.nrtiles;
-  const int H = p.H, RD = p.RD, TR = p.tile_rows, BR = nwaves * TR;
+  const int H = p.H, RD = p.RD;
   const int b0 = bt * BR, nb = min(H, b0 + BR) - b0;  // rows of this workgroup tile
   uint8_t *tf_prev = p.tflags + (size_t)((p.iter + 1) & 1) * p.nframes * p.nrtiles + (size_t)frame * p.nrtiles;
   uint8_t *tf_cur = p.tflags + (size_t)(p.iter & 1) * p.nframes * p.nrtiles + (size_t)frame * p.nrtiles;
@@ -621,86 +645,95 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
   }
   // this wave's rows inside the workgroup tile
   const int w0 = min(wib * TR, nb), n = min((wib + 1) * TR, nb) - w0;
+  const bool owns_last = n > 0 && w0 + n == nb;
   const u64 all_rows = n >= 64 ? ~0ull : ((1ull << n) - 1);
   u64 dirty;  // bit r = row b0 + w0 + r needs (re)evaluation
-  if (p.iter > 0) dirty = ((top && w0 == 0 && n > 0) ? 1ull : 0ull) | ((bot && w0 + n == nb && n > 0) ? (1ull << (n - 1)) : 0ull);
+  if (p.iter > 0) dirty = ((top && w0 == 0 && n > 0) ? 1ull : 0ull) | ((bot && owns_last) ? (1ull << (n - 1)) : 0ull);
   else dirty = all_rows;
   dirty = uniform64(dirty);
   u64 unfilled = p.first_pass ? all_rows : 0ull;  // rows not yet closed under the in-row fill
 
-  constexpr int ROWW = 64 * NW;  // dwords per LDS row
-  u32 *Cl = reinterpret_cast<u32 *>(smem);
-  u32 *Sl = Cl + (size_t)BR * ROWW;                  // rows -1 .. BR  ->  index 0 .. BR+1
-  u32 *bchg = Sl + (size_t)(BR + 2) * ROWW;          // per-wave boundary-change bits of the current round
   u32 *S = p.sbits + (size_t)frame * H * RD;
   const u32 *C = p.cbits + (size_t)frame * H * RD;
-  // Stage the tile with LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave-instruction, no VGPRs, all
-  // in flight at once).  Bit-plane rows are padded to 64*NW dwords, so the rows of a tile are one
-  // contiguous block in HBM and the LDS image is the same bytes.  The two boundary rows of S and
-  // any ragged tail go through registers (rows outside the frame read as 0).
-  {
-    typedef __attribute__((address_space(1))) const void gptr_t;
-    typedef __attribute__((address_space(3))) void lptr_t;
-    constexpr int ROWB = ROWW * 4;          // bytes per row
-    constexpr int RPC = 1024 / ROWB;        // rows per 1 KiB chunk (4, 2 or 1)
-    const int nchunks = nb / RPC;           // whole chunks of interior rows
-    const unsigned char *gC = reinterpret_cast<const unsigned char *>(C + (size_t)b0 * RD);
-    const unsigned char *gS = reinterpret_cast<const unsigned char *>(S + (size_t)b0 * RD);
-    unsigned char *lC = reinterpret_cast<unsigned char *>(Cl), *lS = reinterpret_cast<unsigned char *>(Sl + ROWW);
-    for (int k = wib; k < 2 * nchunks; k += nwaves) {
-      const int ck = k >> 1;
-      if (k & 1) __builtin_amdgcn_global_load_lds((gptr_t *)(gS + (size_t)ck * 1024 + lane * 16), (lptr_t *)(lS + ck * 1024), 16, 0, 0);
-      else __builtin_amdgcn_global_load_lds((gptr_t *)(gC + (size_t)ck * 1024 + lane * 16), (lptr_t *)(lC + ck * 1024), 16, 0, 0);
-    }
-    // rows -1, nb (S only) and the tail rows nchunks*RPC .. nb-1 (both planes): one row per wave turn
-    const int tail0 = nchunks * RPC, nextra = (nb - tail0) + 2;
-    for (int e = wib; e < nextra; e += nwaves) {
-      const int r = e == 0 ? -1 : e == 1 ? nb : tail0 + (e - 2);
-      const int gr = b0 + r;
-      RowBits<NW> sv, cv;
+  // the wave's rows: straight from HBM into registers, all loads in flight at once
+  // (ext_vector types: the compiler keeps them in VGPRs and indexes them with s_set_gpr_idx;
+  //  plain arrays with dynamic stores would be demoted to scratch)
+  typedef u32 RowVec __attribute__((ext_vector_type(TR)));
+  RowVec cr[NW], sr[NW];
 #pragma unroll
-      for (int i = 0; i < NW; ++i) sv.w[i] = cv.w[i] = 0;
-      if (gr >= 0 && gr < H) sv = row_load<NW>(S + (size_t)gr * RD, lane, RD);
-      if (r >= 0 && r < nb) cv = row_load<NW>(C + (size_t)gr * RD, lane, RD);
+  for (int i = 0; i < TR; ++i) {
 #pragma unroll
-      for (int i = 0; i < NW; ++i) Sl[(r + 1) * ROWW + lane * NW + i] = sv.w[i];
-      if (r >= 0 && r < nb)
-#pragma unroll
-        for (int i = 0; i < NW; ++i) Cl[r * ROWW + lane * NW + i] = cv.w[i];
+    for (int j = 0; j < NW; ++j) {
+      const bool ok = i < n && lane * NW + j < RD;
+      const size_t off = (size_t)(b0 + w0 + i) * RD + lane * NW + j;
+      cr[j][i] = ok ? C[off] : 0u;
+      sr[j][i] = ok ? S[off] : 0u;
     }
   }
-  if (threadIdx.x < 32) bchg[threadIdx.x] = 0;
+  u32 *my_first = edge + (2 * wib) * ROWW, *my_last = edge + (2 * wib + 1) * ROWW;
+  u32 *halo_top = edge + (2 * WAVES) * ROWW, *halo_bot = edge + (2 * WAVES + 1) * ROWW;
+  auto publish = [&](u32 *dst, int r) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) dst[lane * NW + j] = sr[j][r];
+  };
+  if (n > 0) {
+    publish(my_first, 0);
+    publish(my_last, n - 1);
+  }
+  if (wib == 0 || owns_last) {  // rows just outside the tile (owned by the neighbouring workgroups, or outside the frame)
+    const int gr = wib == 0 ? b0 - 1 : b0 + nb;
+    RowBits<NW> v;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) v.w[j] = 0;
+    if (wib == 0) {
+      if (gr >= 0) v = row_load<NW>(S + (size_t)gr * RD, lane, RD);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) halo_top[lane * NW + j] = v.w[j];
+    }
+    if (owns_last) {
+      const int gb = b0 + nb;
+      RowBits<NW> vb;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) vb.w[j] = 0;
+      if (gb < H) vb = row_load<NW>(S + (size_t)gb * RD, lane, RD);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) halo_bot[lane * NW + j] = vb.w[j];
+    }
+  }
+  if (threadIdx.x < 24) bchg[threadIdx.x] = 0;
   __syncthreads();
+  const u32 *up_src = wib == 0 ? halo_top : edge + (2 * (wib - 1) + 1) * ROWW;  // row above my first row
+  const u32 *dn_src = owns_last ? halo_bot : edge + (2 * (wib + 1)) * ROWW;      // row below my last row
 
   // Row worklist per wave, lowest dirty row first: a downward sweep that steps back up whenever a
   // row's new strong bits reach candidates of the row above.  Work is proportional to the rows that
-  // change.  Waves exchange their boundary rows through the shared LDS tile between rounds.
+  // change.  Waves exchange their boundary rows through LDS between rounds.
   u64 changed = 0;
-  auto lds_row = [&](const u32 *base, int idx) {
-    RowBits<NW> v;
-#pragma unroll
-    for (int i = 0; i < NW; ++i) v.w[i] = base[idx * ROWW + lane * NW + i];
-    return v;
-  };
   for (int round = 0; round < (p.debug_skip ? 0 : 4096); ++round) {
     u64 round_changed = 0;
     while (dirty) {
       const int r = __builtin_ctzll(dirty);
       dirty &= dirty - 1;
-      const int br = w0 + r;  // row inside the workgroup tile
-      const RowBits<NW> up = lds_row(Sl, br), s = lds_row(Sl, br + 1), dn = lds_row(Sl, br + 2), c = lds_row(Cl, br);
+      RowBits<NW> up, dn, s, c;
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        up.w[j] = r == 0 ? up_src[lane * NW + j] : sr[j][r > 0 ? r - 1 : 0];
+        dn.w[j] = r == n - 1 ? dn_src[lane * NW + j] : sr[j][r + 1 < TR ? r + 1 : r];
+        s.w[j] = sr[j][r];
+        c.w[j] = cr[j][r];
+      }
       RowBits<NW> nbr;
 #pragma unroll
-      for (int i = 0; i < NW; ++i) nbr.w[i] = up.w[i] | dn.w[i];
+      for (int j = 0; j < NW; ++j) nbr.w[j] = up.w[j] | dn.w[j];
       const RowBits<NW> d = row_dilate<NW>(nbr);
       RowBits<NW> seed;
       bool grew = false, hs = false, hc = false;
 #pragma unroll
-      for (int i = 0; i < NW; ++i) {
-        seed.w[i] = s.w[i] | (c.w[i] & d.w[i]);
-        grew = grew || (seed.w[i] != s.w[i]);
-        hs = hs || s.w[i] != 0;
-        hc = hc || (c.w[i] & ~s.w[i]) != 0;
+      for (int j = 0; j < NW; ++j) {
+        seed.w[j] = s.w[j] | (c.w[j] & d.w[j]);
+        grew = grew || (seed.w[j] != s.w[j]);
+        hs = hs || s.w[j] != 0;
+        hc = hc || (c.w[j] & ~s.w[j]) != 0;
       }
       bool todo = __ballot(grew) != 0;
       if ((unfilled >> r) & 1) {
@@ -711,11 +744,12 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
       const RowBits<NW> f = row_fill<NW>(c, seed);
       bool ch = false;
 #pragma unroll
-      for (int i = 0; i < NW; ++i) ch = ch || (f.w[i] != s.w[i]);
+      for (int j = 0; j < NW; ++j) ch = ch || (f.w[j] != s.w[j]);
       if (__ballot(ch) == 0) continue;
 #pragma unroll
-      for (int i = 0; i < NW; ++i) Sl[(br + 1) * ROWW + lane * NW + i] = f.w[i];
-      wave_lds_sync();
+      for (int j = 0; j < NW; ++j) sr[j][r] = f.w[j];
+      if (r == 0) publish(my_first, 0);
+      if (r == n - 1) publish(my_last, n - 1);
       round_changed |= 1ull << r;
       dirty |= ((1ull << r) >> 1) | (((1ull << r) << 1) & all_rows);
     }
@@ -724,11 +758,10 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
     __syncthreads();
     if (n > 0) {
       if (wib > 0 && (bchg[wib - 1] & 2u)) dirty |= 1ull;
-      if (wib + 1 < nwaves && (bchg[wib + 1] & 1u)) dirty |= 1ull << (n - 1);
+      if (!owns_last && wib + 1 < WAVES && (bchg[wib + 1] & 1u)) dirty |= 1ull << (n - 1);
     }
     dirty = uniform64(dirty);
     // workgroup-wide "any wave has work": OR through an LDS word per round parity
-    // (no __syncthreads_or: its hidden static LDS would shift the dynamic region)
     if (lane == 0 && dirty != 0) atomicOr(&bchg[18 + (round & 1)], 1u);
     __syncthreads();
     const bool more = __builtin_amdgcn_readfirstlane(bchg[18 + (round & 1)]) != 0;
@@ -740,9 +773,9 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
   for (u64 m = changed; m; m &= m - 1) {
     const int r = __builtin_ctzll(m);
 #pragma unroll
-    for (int i = 0; i < NW; ++i) {
-      const int dd = lane * NW + i;
-      if (dd < RD) S[(size_t)(b0 + w0 + r) * RD + dd] = Sl[(w0 + r + 1) * ROWW + lane * NW + i];
+    for (int j = 0; j < NW; ++j) {
+      const int dd = lane * NW + j;
+      if (dd < RD) S[(size_t)(b0 + w0 + r) * RD + dd] = sr[j][r];
     }
   }
   // fused expand (removeCandidates + output copy, cannyEdgeD.cu:379-395): strong bits -> 255, rest 0.
@@ -752,10 +785,22 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
     uint8_t *obase = p.out + (size_t)frame * p.out_frame_stride;
     for (u64 m = p.iter == 0 ? all_rows : changed; m; m &= m - 1) {
       const int r = __builtin_ctzll(m);
-      const unsigned short *bits = reinterpret_cast<const unsigned short *>(Sl + (size_t)(w0 + r + 1) * ROWW);
       uint8_t *orow = obase + (size_t)(b0 + w0 + r) * p.out_pitch;
-      for (int c0 = lane * 16; c0 < p.W; c0 += 1024) {
-        const u32 b = bits[c0 >> 4];
+      u32 rowv[NW];
+#pragma unroll
+      for (int j = 0; j < NW; ++j) rowv[j] = sr[j][r];
+      for (int pass = 0; pass * 1024 < p.W; ++pass) {
+        // this lane writes px [1024*pass + 16*lane, +16): half-word 64*pass + lane of the row
+        const int D = 32 * pass + (lane >> 1);  // dword holding it
+        u32 x = 0;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          const u32 t = __shfl(rowv[j], D / NW);
+          x = (D % NW) == j ? t : x;
+        }
+        const u32 b = (x >> (16 * (lane & 1))) & 0xFFFFu;
+        const int c0 = pass * 1024 + lane * 16;
+        if (c0 >= p.W) continue;
         u32 v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
@@ -772,7 +817,7 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
     }
   }
   const bool first_changed = n > 0 && w0 == 0 && (changed & 1ull);
-  const bool last_changed = n > 0 && w0 + n == nb && ((changed >> (n - 1)) & 1ull);
+  const bool last_changed = owns_last && ((changed >> (n - 1)) & 1ull);
   if (lane == 0 && (first_changed || last_changed)) atomicOr(&bchg[16], (first_changed ? 1u : 0u) | (last_changed ? 2u : 0u));
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -780,7 +825,7 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
     tf_cur[bt] = (uint8_t)vis;
     if (vis) atomicOr(&p.flags[p.iter], 1u);
   }
-  if (lane == 0 && p.stats && n > 0) {  // diagnostics: changed rows summed / max over wave tiles, active wave tiles
+  if (lane == 0 && p.stats && n > 0) {  // diagnostics (opt-in): changed rows summed / max over wave tiles, active wave tiles
     const u32 nch = (u32)__builtin_popcountll(changed);
     atomicAdd(&p.stats[0], nch);
     atomicMax(&p.stats[1], nch);
@@ -790,31 +835,16 @@ __global__ __launch_bounds__(1024) void k_hyst(const HystParams p)
 
 hipError_t launch_hyst(const HystParams &p, hipStream_t s)
 {
-  const dim3 grid((unsigned)(p.nframes * p.nrtiles)), block(64 * p.waves);
-  const size_t lds = hyst_lds_bytes(p.RD, p.tile_rows * p.waves);
-  if (p.tile_rows > 64 || p.waves < 1 || p.waves > 16 || lds > 160 * 1024 || p.RD > 256) {
-    fprintf(stderr, "launch_hyst: unsupported geometry lds=%zu RD=%d tile_rows=%d\n", lds, p.RD, p.tile_rows);
-    return hipErrorInvalidValue;
-  }
-  static bool attr_done = false;
-  if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hyst<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hyst<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hyst<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_done = true;
-  }
-  const int nw = hyst_nw(p.RD);
-  if (nw == 1) hipLaunchKernelGGL(k_hyst<1>, grid, block, lds, s, p);
-  else if (nw == 2) hipLaunchKernelGGL(k_hyst<2>, grid, block, lds, s, p);
-  else hipLaunchKernelGGL(k_hyst<4>, grid, block, lds, s, p);
-  const hipError_t e = hipGetLastError();
-  if (e != hipSuccess) {
-    hipFuncAttributes fa{};
-    hipError_t e2 = hipFuncGetAttributes(&fa, reinterpret_cast<const void *>(&k_hyst<1>));
-    fprintf(stderr, "k_hyst<1> attrs (%s): static lds %zu, maxDyn %d, regs %d, maxThreads %d\n", hipGetErrorString(e2), fa.sharedSizeBytes, fa.maxDynamicSharedSizeBytes, fa.numRegs, fa.maxThreadsPerBlock);
-  }
-  if (e != hipSuccess) fprintf(stderr, "launch_hyst failed: %s grid=%u lds=%zu RD=%d tile_rows=%d nrtiles=%d nframes=%d iter=%d\n", hipGetErrorString(e), grid.x, lds, p.RD, p.tile_rows, p.nrtiles, p.nframes, p.iter);
-  return e;
+  const HystGeom g = hyst_geom(p.RD);
+  if (p.RD > 256 || p.tile_rows != g.tr || p.waves != g.waves) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)(p.nframes * p.nrtiles)), block(64 * g.waves);
+  if (g.nw == 1 && g.tr == 32 && g.waves == 8) hipLaunchKernelGGL((k_hyst<1, 32, 8>), grid, block, 0, s, p);
+  else if (g.nw == 1 && g.tr == 32 && g.waves == 4) hipLaunchKernelGGL((k_hyst<1, 32, 4>), grid, block, 0, s, p);
+  else if (g.nw == 1 && g.tr == 16 && g.waves == 8) hipLaunchKernelGGL((k_hyst<1, 16, 8>), grid, block, 0, s, p);
+  else if (g.nw == 1 && g.tr == 32 && g.waves == 16) hipLaunchKernelGGL((k_hyst<1, 32, 16>), grid, block, 0, s, p);
+  else if (g.nw == 2) hipLaunchKernelGGL((k_hyst<2, 32, 8>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((k_hyst<4, 16, 8>), grid, block, 0, s, p);
+  return hipGetLastError();
 }
 
 // =================================================================================================

@@ -202,17 +202,10 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   const int K = c->hyst_launches;
   HystParams hp{};
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags; hp.tflags = s.d_tflags;
-  // one workgroup per (frame, tile of `waves` x tile_rows rows) staged in LDS
-  {
-    if (const char *e = getenv("HC_HYST_ROWS")) small_tiles = atoi(e) <= 128;
-    int br = small_tiles ? 128 : 256;  // rows per workgroup tile (128: leaves LDS for co-resident front-kernel workgroups)
-    const size_t cap = small_tiles ? 72 * 1024 : 150 * 1024;
-    while (br > 32 && hyst_lds_bytes(c->RD, br) > cap) br /= 2;
-    while (br > 32 && br / 2 >= c->H) br /= 2;  // small frames: do not stage empty rows
-    hp.waves = std::min(c->hyst_waves, br / 8);
-    hp.tile_rows = br / hp.waves;
-    hp.nrtiles = (c->H + br - 1) / br;
-  }
+  // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
+  hyst_tile_geometry(c->RD, &hp.tile_rows, &hp.waves);
+  hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
+  (void)small_tiles;
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
   hp.debug_skip = getenv("HC_DEBUG_SKIP_HYST") ? 1 : 0;
