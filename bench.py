@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--hyst-launches", type=int, default=4)
-    ap.add_argument("--no-pipeline", action="store_true", help="do not overlap run i+1's front kernel with run i's hysteresis")
+    ap.add_argument("--pipeline", action="store_true", help="HC_OPT_PIPELINE: overlap run i+1's front kernel with run i's hysteresis (measured: no gain, both kernels compete for the same CUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -77,7 +77,7 @@ def main():
     ctx = api.Context(W, H, 1, B, api.MODE_R, device=local)
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
-    ctx.set_option(api.OPT_PIPELINE, 0 if a.no_pipeline else 1)
+    ctx.set_option(api.OPT_PIPELINE, 1 if a.pipeline else 0)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -130,7 +130,7 @@ def main():
             "data": f"synthetic ({a.kind}, {min(a.unique, B)} distinct frames tiled to the batch)",
             "config": {"workload": f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU",
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",
-                       "pipeline": not a.no_pipeline},
+                       "pipeline": bool(a.pipeline)},
             "e2e_alg_GBps": round(2.0 * W * H * frames_total / elapsed / 1e9, 1),
             "roofline": {
                 "bound": "hbm", "kernel": "k_front", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
