@@ -23,7 +23,8 @@ constexpr int STRIP_HALO = PX_PER_LANE;             // 4 columns = one lane
 // bit c of a row <-> column c, rows padded to RD dwords.  A strip's 248 valid columns are 31 whole
 // bytes, so each wave-row of k_front stores its 31 bytes at byte offset strip*31 of the row.
 struct FrontParams {
-  const uint8_t *in;       // mono u8 frames, pitched
+  const uint8_t *in;       // u8 frames, pitched: mono, or interleaved BGR when bgr != 0 (stage 0 fused into the load)
+  int bgr;
   size_t in_pitch;         // bytes per row   (multiple of 4)
   size_t in_frame_stride;  // bytes per frame (multiple of 4)
   u32 *sbits, *cbits;      // bit planes [frame][H][RD]

@@ -121,6 +121,7 @@ size_t front_lds_bytes(int chunk_rows) { return (size_t)4 * ((chunk_rows + 4) * 
 
 // literal reference chain for one pixel (cannyEdgeD.cu:102-115): 25 fused multiply-adds from 0.0f in
 // r-major / c-minor order, truncation.  Only used for the rare undecidable pixels.
+template <bool BGR = false>
 static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_t pitch, int W, int H, int row, int col)
 {
   float f = 0.0f;
@@ -131,14 +132,19 @@ static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_
     for (int c = 0; c < 5; ++c) {
       const int cc = col - 2 + c;
       float px = 0.0f;
-      if (rr >= 0 && rr < H && cc >= 0 && cc < W) px = (float)frame[(size_t)rr * pitch + cc];
+      if (rr >= 0 && rr < H && cc >= 0 && cc < W) {
+        if (BGR) {  // stage 0 on the fly: (b*7 + g*38 + r*19) >> 6 (cannyEdgeD.cu:17-19,67)
+          const uint8_t *q = frame + (size_t)rr * pitch + 3 * (size_t)cc;
+          px = (float)((q[0] * 7 + q[1] * 38 + q[2] * 19) >> 6);
+        } else px = (float)frame[(size_t)rr * pitch + cc];
+      }
       f = __builtin_fmaf(c_gk[r * 5 + c], px, f);
     }
   }
   return (u32)(int)f;
 }
 
-template <int CHUNK>
+template <int CHUNK, bool BGR>
 __global__ __launch_bounds__(256) void k_front(const FrontParams p)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   const u32 oknib = oknib1 | (oknib1 << 8);
   const bool col_any = cmask != 0;
   const uint8_t *frame_base = p.in + (size_t)frame * p.in_frame_stride;
-  const uint8_t *src = frame_base + c0;  // dereferenced only where col_any
+  const uint8_t *src = frame_base + (BGR ? 3 : 1) * c0;  // dereferenced only where col_any
 
   // ------------------------------------------------------------------ phase 1: blur rows -> LDS
   // Packed u16 arithmetic, two pixels per VALU op.  With K the 5x5 integer kernel (sum 159) and
@@ -194,7 +200,21 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
 
   auto load_row = [&](int row) -> u32 {
     u32 v = 0;
-    if (row >= 0 && row < H && col_any) v = *reinterpret_cast<const u32 *>(src + (size_t)row * p.in_pitch);
+    if (row >= 0 && row < H && col_any) {
+      if (BGR) {
+        // 4 interleaved BGR pixels = 12 bytes = 3 dwords; stage 0 (cannyEdgeD.cu:53-69) fused into the
+        // load: each pixel's 3 bytes are aligned into one dword and reduced by one v_dot4 with the
+        // weights (7, 38, 19, 0); sum of weights = 64, so the reference's min(255, .) never triggers
+        const u32 *q = reinterpret_cast<const u32 *>(src + (size_t)row * p.in_pitch);
+        const u32 d0 = q[0], d1 = q[1], d2 = q[2];
+        const u32 wts = 0x00132607u;
+        const u32 m0 = __builtin_amdgcn_udot4(d0, wts, 0u, false) >> 6;
+        const u32 m1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), wts, 0u, false) >> 6;
+        const u32 m2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), wts, 0u, false) >> 6;
+        const u32 m3 = __builtin_amdgcn_udot4(d2 >> 8, wts, 0u, false) >> 6;
+        v = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+      } else v = *reinterpret_cast<const u32 *>(src + (size_t)row * p.in_pitch);
+    }
     return v;
   };
 
@@ -287,7 +307,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
         const u32 a = queue[e];
         const int row = r0 - 2 + (int)(a >> 8);
         const int col = strip * STRIP_W - STRIP_HALO + (int)(a & 255u);
-        blur_s[a] = (unsigned char)gauss_chain_px(frame_base, p.in_pitch, W, H, row, col);
+        blur_s[a] = (unsigned char)gauss_chain_px<BGR>(frame_base, p.in_pitch, W, H, row, col);
       }
     }
   } else {
@@ -296,7 +316,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
       const int row = r0 - 2 + (e >> 8);
       const int col = strip * STRIP_W - STRIP_HALO + (e & 255);
       if (row >= 0 && row < H && col >= 0 && col < W)
-        blur_s[e] = (unsigned char)gauss_chain_px(frame_base, p.in_pitch, W, H, row, col);
+        blur_s[e] = (unsigned char)gauss_chain_px<BGR>(frame_base, p.in_pitch, W, H, row, col);
     }
   }
   wave_lds_sync();
@@ -423,23 +443,29 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   }
 }
 
-hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s)
+template <bool BGR>
+static hipError_t launch_front_t(const FrontParams &p, int chunk_rows, hipStream_t s)
 {
   const int nblocks = (p.total_items + 3) / 4;
   const size_t lds = front_lds_bytes(chunk_rows);
   static bool attr_done = false;
   if (!attr_done) {  // chunk 64 needs more than the default 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes(64));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<64, BGR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes(64));
     attr_done = true;
   }
   switch (chunk_rows) {
-    case 8: hipLaunchKernelGGL(k_front<8>, dim3(nblocks), dim3(256), lds, s, p); break;
-    case 16: hipLaunchKernelGGL(k_front<16>, dim3(nblocks), dim3(256), lds, s, p); break;
-    case 32: hipLaunchKernelGGL(k_front<32>, dim3(nblocks), dim3(256), lds, s, p); break;
-    case 64: hipLaunchKernelGGL(k_front<64>, dim3(nblocks), dim3(256), lds, s, p); break;
+    case 8: hipLaunchKernelGGL((k_front<8, BGR>), dim3(nblocks), dim3(256), lds, s, p); break;
+    case 16: hipLaunchKernelGGL((k_front<16, BGR>), dim3(nblocks), dim3(256), lds, s, p); break;
+    case 32: hipLaunchKernelGGL((k_front<32, BGR>), dim3(nblocks), dim3(256), lds, s, p); break;
+    case 64: hipLaunchKernelGGL((k_front<64, BGR>), dim3(nblocks), dim3(256), lds, s, p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
+}
+
+hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s)
+{
+  return p.bgr ? launch_front_t<true>(p, chunk_rows, s) : launch_front_t<false>(p, chunk_rows, s);
 }
 
 // =================================================================================================

@@ -264,7 +264,9 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   // stage 0 (cannyEdgeH.cu:214-227); 1-channel input skips it (the reference's mono path is broken, SURVEY §3 ii)
   const uint8_t *mono = src;
   size_t mp = sp, mfs = sfs;
-  if (c->C == 3) {
+  // the fused kernel converts BGR while loading (needs whole 12-byte pixel groups inside each row)
+  const bool fuse_bgr = c->C == 3 && stage == HC_STAGE_HYSTER && sp >= round_up((size_t)W, 4) * 3;
+  if (c->C == 3 && !fuse_bgr) {
     if (stage == HC_STAGE_MONO) {
       HIPCK(launch_gray(src, sp, sfs, dst, dp, dfs, W, H, n, sf));
     } else {
@@ -278,7 +280,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
 
   if (stage == HC_STAGE_HYSTER) {
     FrontParams fp{};
-    fp.in = mono; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = s.d_sbits; fp.cbits = s.d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
+    fp.in = mono; fp.bgr = fuse_bgr ? 1 : 0; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = s.d_sbits; fp.cbits = s.d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
     const int chunk = c->chunk ? c->chunk : 16;
     fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n;
     fp.total_items = n * fp.nstrips * fp.nchunks;
@@ -350,7 +352,7 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   // bit-plane row: covers every strip's 31 bytes, padded to a multiple of 64 dwords (one LDS row per wave)
   {
     const size_t need = std::max<size_t>((size_t)(width + 31) / 32, ((size_t)c->nstrips * 31 + 3) / 4);
-    if (need > 256) { fail(HC_E_ARG, "hc_create: width above 8192 is not supported"); delete c; return nullptr; }
+    if (need > 256) { fail(HC_E_ARG, "hc_create: width above 8184 is not supported"); delete c; return nullptr; }
     c->RD = need <= 64 ? 64 : need <= 128 ? 128 : 256;  // 64 * NW dwords, NW in {1, 2, 4}
   }
   auto ok = [&](hipError_t e, const char *what) {
@@ -363,7 +365,8 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   good = good && ok(hipStreamCreateWithFlags(&c->s_hyst, hipStreamNonBlocking), "hipStreamCreate");
   good = good && ok(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming), "hipEventCreate");
   c->stream = c->own_stream;
-  good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, (size_t)width * channels, height, max_batch) == HC_OK;
+  // (a BGR row is read in 12-byte groups of 4 pixels: keep room for the ragged last group)
+  good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, round_up((size_t)width, 4) * channels, height, max_batch) == HC_OK;
   good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch) == HC_OK;
   if (good && channels == 3) good = alloc_frames(&c->d_mono, &c->mono_pitch, &c->mono_fs, (size_t)width, height, max_batch) == HC_OK;
   good = good && alloc_slot(c, c->slot[0]) == HC_OK;

@@ -74,6 +74,28 @@ def test_bgr_input(oracle):
             _diff(ctx.process(img, stage)[0], want[key], f"bgr stage {stage.name}")
 
 
+def test_bgr_fused_and_fallback(oracle):
+    """BGR input: stage 0 is fused into the front kernel's load when rows hold whole 4-pixel groups
+    (internal buffers always do); a tight caller pitch with W % 4 != 0 takes the k_gray path."""
+    import torch
+    rng = np.random.default_rng(11)
+    for (w, h) in ((1920, 64), (641, 33), (250, 40)):
+        img = np.ascontiguousarray(rng.integers(0, 256, (2, h, w, 3), dtype=np.uint8))
+        img[0, :, :, :] = np.repeat(synth.natural(w, h, 5)[:, :, None], 3, axis=2)  # grey-ish frame with structure
+        img[0, :, :, 1] = np.clip(img[0, :, :, 1].astype(int) + 20, 0, 255)
+        want = [oracle.canny_r(img[f], 10, 40) for f in range(2)]
+        with api.Context(w, h, 3, 2) as ctx:
+            got = ctx.process(img)                       # hc_upload path (internal pitched buffer): fused
+            for f in range(2):
+                _diff(got[f], want[f], f"bgr fused {w}x{h} frame {f}")
+            d_in = torch.from_numpy(img).cuda()          # tight pitch 3*w
+            d_out = torch.zeros((2, h, w), dtype=torch.uint8, device="cuda")
+            ctx.run_device(d_in.data_ptr(), 3 * w, 3 * w * h, d_out.data_ptr(), w, w * h, 2)
+            ctx.sync()
+            for f in range(2):
+                _diff(d_out[f].cpu().numpy(), want[f], f"bgr run_device {w}x{h} frame {f}")
+
+
 @pytest.mark.parametrize("low,high", [(0, 0), (0, 255), (255, 255), (5, 250), (40, 10), (100, 101)])
 def test_thresholds(oracle, low, high):
     img = synth.steps(300, 200, 250, "diagonal")
@@ -85,6 +107,26 @@ def test_thresholds(oracle, low, high):
         want = oracle.canny_r(img, lo, hi, stages=True)
         _diff(ctx.process(img, api.CannyStage.THRESH)[0], want["thresh"], "thresh")
         _diff(ctx.process(img, api.CannyStage.HYSTER)[0], want["edges"], "edges")
+
+
+@pytest.mark.parametrize("w,h", [(3840, 96), (4097, 70), (7680, 48), (8184, 33), (2049, 40)])
+def test_wide_frames(oracle, w, h):
+    """4K / 8K row widths: the bit-plane rows span 2 or 4 dwords per lane in the hysteresis kernel."""
+    img = synth.natural(w, h, 300 + w)
+    img[:, w // 2 - 700: w // 2 + 700] = synth.serpentine(1400, h, pitch=10, margin=3)
+    want = oracle.canny_r(img, 10, 40, stages=True)
+    with api.Context(w, h, 1, 1) as ctx:
+        _diff(ctx.process(img, api.CannyStage.THRESH)[0], want["thresh"], f"{w}x{h} thresh")
+        _diff(ctx.process(img, api.CannyStage.HYSTER)[0], want["edges"], f"{w}x{h} edges")
+
+
+def test_4k_frame(oracle):
+    img = synth.natural(3840, 2160, 4242)
+    want = oracle.canny_r(img, 10, 40)
+    with api.Context(3840, 2160, 1, 2) as ctx:
+        got = ctx.process(np.stack([img, img[::-1].copy()]))
+        _diff(got[0], want, "4K frame 0")
+        _diff(got[1], oracle.canny_r(img[::-1].copy(), 10, 40), "4K frame 1")
 
 
 def test_saturate_option(oracle):
