@@ -41,6 +41,7 @@ CANNY_STAGES = {
 MODE_R, MODE_O = 0, 1
 OPT_NMS_SATURATE = 1
 OPT_PIPELINE = 2
+OPT_PER_CHANNEL = 3
 
 # every symbol include/hipcanny.h declares
 ABI_SYMBOLS = [
@@ -193,6 +194,7 @@ class Context:
         _ck(self.lib.hc_run(self.handle, int(final_stage), int(nframes)))
 
     def download(self, nframes=1):
+        """nframes output images (in per-channel mode: 3 per input frame)."""
         out = np.empty((nframes, self.h, self.w), np.uint8)
         _ck(self.lib.hc_download(self.handle, out.ctypes.data, self.w, self.w * self.h, nframes))
         return out

@@ -121,8 +121,9 @@ size_t front_lds_bytes(int chunk_rows) { return (size_t)4 * ((chunk_rows + 4) * 
 
 // literal reference chain for one pixel (cannyEdgeD.cu:102-115): 25 fused multiply-adds from 0.0f in
 // r-major / c-minor order, truncation.  Only used for the rare undecidable pixels.
-template <bool BGR = false>
-static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_t pitch, int W, int H, int row, int col)
+// IN: how a pixel is read -- 0 mono plane, 1 BGR -> grey (stage 0 fused), 2 channel `ch` of interleaved 3-channel data
+template <int IN = 0>
+static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_t pitch, int W, int H, int row, int col, int ch = 0)
 {
   float f = 0.0f;
 #pragma unroll
@@ -133,10 +134,11 @@ static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_
       const int cc = col - 2 + c;
       float px = 0.0f;
       if (rr >= 0 && rr < H && cc >= 0 && cc < W) {
-        if (BGR) {  // stage 0 on the fly: (b*7 + g*38 + r*19) >> 6 (cannyEdgeD.cu:17-19,67)
+        if (IN == 1) {  // stage 0 on the fly: (b*7 + g*38 + r*19) >> 6 (cannyEdgeD.cu:17-19,67)
           const uint8_t *q = frame + (size_t)rr * pitch + 3 * (size_t)cc;
           px = (float)((q[0] * 7 + q[1] * 38 + q[2] * 19) >> 6);
-        } else px = (float)frame[(size_t)rr * pitch + cc];
+        } else if (IN == 2) px = (float)frame[(size_t)rr * pitch + 3 * (size_t)cc + ch];
+        else px = (float)frame[(size_t)rr * pitch + cc];
       }
       f = __builtin_fmaf(c_gk[r * 5 + c], px, f);
     }
@@ -144,7 +146,7 @@ static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_
   return (u32)(int)f;
 }
 
-template <int CHUNK, bool BGR>
+template <int CHUNK, int IN>
 __global__ __launch_bounds__(256) void k_front(const FrontParams p)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -158,7 +160,9 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   if (item >= p.total_items) return;
   const int chunk = item % p.nchunks;
   const int strip = (item / p.nchunks) % p.nstrips;
-  const int frame = item / (p.nchunks * p.nstrips);
+  // per-channel mode: an output "frame" is one channel of an input frame (3 edge maps per input frame)
+  const int frame = item / (p.nchunks * p.nstrips);           // output frame = bit-plane index
+  const int in_frame = IN == 2 ? frame / 3 : frame, ch = IN == 2 ? frame % 3 : 0;
   const int W = p.W, H = p.H;
   const int r0 = chunk * CHUNK;
   const int c0 = strip * STRIP_W - STRIP_HALO + lane * PX_PER_LANE;
@@ -182,8 +186,11 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   const u32 oknib1 = (lane >= 1 && lane <= 62) ? ((cmask & 1u) | ((cmask >> 7) & 2u) | ((cmask >> 14) & 4u) | ((cmask >> 21) & 8u)) : 0u;
   const u32 oknib = oknib1 | (oknib1 << 8);
   const bool col_any = cmask != 0;
-  const uint8_t *frame_base = p.in + (size_t)frame * p.in_frame_stride;
-  const uint8_t *src = frame_base + (BGR ? 3 : 1) * c0;  // dereferenced only where col_any
+  const uint8_t *frame_base = p.in + (size_t)in_frame * p.in_frame_stride;
+  const uint8_t *src = frame_base + (IN ? 3 : 1) * c0;  // dereferenced only where col_any
+  // per-channel mode: byte selectors that pull channel ch of 4 pixels out of 12 interleaved bytes
+  const u32 selA = ch == 0 ? 0x0c060300u : ch == 1 ? 0x0c070401u : 0x0c0c0502u;  // from {d1,d0}: bytes ch, ch+3, (ch+6 if < 8)
+  const u32 selB = ch == 0 ? 0x05020100u : ch == 1 ? 0x06020100u : 0x07040100u;  // from {d2,t}: t.b0, t.b1, (t.b2 | d2 byte), d2 byte
 
   // ------------------------------------------------------------------ phase 1: blur rows -> LDS
   // Packed u16 arithmetic, two pixels per VALU op.  With K the 5x5 integer kernel (sum 159) and
@@ -201,7 +208,11 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   auto load_row = [&](int row) -> u32 {
     u32 v = 0;
     if (row >= 0 && row < H && col_any) {
-      if (BGR) {
+      if (IN == 2) {
+        const u32 *q = reinterpret_cast<const u32 *>(src + (size_t)row * p.in_pitch);
+        const u32 t = __builtin_amdgcn_perm(q[1], q[0], selA);
+        v = __builtin_amdgcn_perm(q[2], t, selB);
+      } else if (IN == 1) {
         // 4 interleaved BGR pixels = 12 bytes = 3 dwords; stage 0 (cannyEdgeD.cu:53-69) fused into the
         // load: each pixel's 3 bytes are aligned into one dword and reduced by one v_dot4 with the
         // weights (7, 38, 19, 0); sum of weights = 64, so the reference's min(255, .) never triggers
@@ -307,7 +318,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
         const u32 a = queue[e];
         const int row = r0 - 2 + (int)(a >> 8);
         const int col = strip * STRIP_W - STRIP_HALO + (int)(a & 255u);
-        blur_s[a] = (unsigned char)gauss_chain_px<BGR>(frame_base, p.in_pitch, W, H, row, col);
+        blur_s[a] = (unsigned char)gauss_chain_px<IN>(frame_base, p.in_pitch, W, H, row, col, ch);
       }
     }
   } else {
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
       const int row = r0 - 2 + (e >> 8);
       const int col = strip * STRIP_W - STRIP_HALO + (e & 255);
       if (row >= 0 && row < H && col >= 0 && col < W)
-        blur_s[e] = (unsigned char)gauss_chain_px<BGR>(frame_base, p.in_pitch, W, H, row, col);
+        blur_s[e] = (unsigned char)gauss_chain_px<IN>(frame_base, p.in_pitch, W, H, row, col, ch);
     }
   }
   wave_lds_sync();
@@ -443,21 +454,21 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   }
 }
 
-template <bool BGR>
+template <int IN>
 static hipError_t launch_front_t(const FrontParams &p, int chunk_rows, hipStream_t s)
 {
   const int nblocks = (p.total_items + 3) / 4;
   const size_t lds = front_lds_bytes(chunk_rows);
   static bool attr_done = false;
   if (!attr_done) {  // chunk 64 needs more than the default 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<64, BGR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes(64));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<64, IN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes(64));
     attr_done = true;
   }
   switch (chunk_rows) {
-    case 8: hipLaunchKernelGGL((k_front<8, BGR>), dim3(nblocks), dim3(256), lds, s, p); break;
-    case 16: hipLaunchKernelGGL((k_front<16, BGR>), dim3(nblocks), dim3(256), lds, s, p); break;
-    case 32: hipLaunchKernelGGL((k_front<32, BGR>), dim3(nblocks), dim3(256), lds, s, p); break;
-    case 64: hipLaunchKernelGGL((k_front<64, BGR>), dim3(nblocks), dim3(256), lds, s, p); break;
+    case 8: hipLaunchKernelGGL((k_front<8, IN>), dim3(nblocks), dim3(256), lds, s, p); break;
+    case 16: hipLaunchKernelGGL((k_front<16, IN>), dim3(nblocks), dim3(256), lds, s, p); break;
+    case 32: hipLaunchKernelGGL((k_front<32, IN>), dim3(nblocks), dim3(256), lds, s, p); break;
+    case 64: hipLaunchKernelGGL((k_front<64, IN>), dim3(nblocks), dim3(256), lds, s, p); break;
     default: return hipErrorInvalidValue;
   }
   return hipGetLastError();
@@ -465,7 +476,7 @@ static hipError_t launch_front_t(const FrontParams &p, int chunk_rows, hipStream
 
 hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s)
 {
-  return p.bgr ? launch_front_t<true>(p, chunk_rows, s) : launch_front_t<false>(p, chunk_rows, s);
+  return p.bgr == 2 ? launch_front_t<2>(p, chunk_rows, s) : p.bgr == 1 ? launch_front_t<1>(p, chunk_rows, s) : launch_front_t<0>(p, chunk_rows, s);
 }
 
 // =================================================================================================

@@ -65,6 +65,7 @@ struct hc_ctx {
   Slot slot[2];
   int cur = 0;
   bool pipeline = false;
+  int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
   int RD = 0;
   int nstrips = 0, chunk = 0, hyst_launches = 6, hyst_waves = 8;
   int last_work_launches = 0, last_continued = 0;
@@ -104,13 +105,14 @@ int ensure_stage_scratch(hc_ctx *c)
 int alloc_slot(hc_ctx *c, Slot &s)
 {
   if (s.d_sbits) return HC_OK;
-  const size_t plane_bytes = sizeof(u32) * (size_t)c->RD * c->H * c->max_batch;
+  const size_t out_frames = (size_t)c->max_batch * (c->per_channel ? 3 : 1);
+  const size_t plane_bytes = sizeof(u32) * (size_t)c->RD * c->H * out_frames;
   HIPCK(hipMalloc((void **)&s.d_sbits, plane_bytes));
   HIPCK(hipMalloc((void **)&s.d_cbits, plane_bytes));
   // row padding beyond the strips' bytes is never written by the kernels and must read as 0
   HIPCK(hipMemset(s.d_sbits, 0, plane_bytes));
   HIPCK(hipMemset(s.d_cbits, 0, plane_bytes));
-  HIPCK(hipMalloc((void **)&s.d_tflags, (size_t)2 * c->max_batch * ((c->H + 7) / 8 + 1)));
+  HIPCK(hipMalloc((void **)&s.d_tflags, (size_t)2 * out_frames * ((c->H + 7) / 8 + 1)));
   HIPCK(hipMalloc((void **)&s.d_flags, sizeof(u32) * FLAG_WORDS));
   HIPCK(hipHostMalloc((void **)&s.h_flags, sizeof(u32) * FLAG_WORDS, hipHostMallocDefault));
   HIPCK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
@@ -230,7 +232,9 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
 int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_t *out, size_t out_pitch, size_t out_fs, int n, int stage)
 {
   if (c->mode != HC_MODE_R) return fail(HC_E_ARG, "mode O is not built into this library version");
+  if (c->per_channel && stage != HC_STAGE_HYSTER) return fail(HC_E_ARG, "per-channel mode only produces the final edge maps (HC_STAGE_HYSTER)");
   const int W = c->W, H = c->H;
+  const int n_out = c->per_channel ? 3 * n : n;  // output frames (= bit-plane frames)
   const bool piped = c->pipeline && stage == HC_STAGE_HYSTER;
   Slot &s = c->slot[piped ? c->cur : 0];
   if (piped) {
@@ -265,7 +269,9 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   const uint8_t *mono = src;
   size_t mp = sp, mfs = sfs;
   // the fused kernel converts BGR while loading (needs whole 12-byte pixel groups inside each row)
-  const bool fuse_bgr = c->C == 3 && stage == HC_STAGE_HYSTER && sp >= round_up((size_t)W, 4) * 3;
+  const bool whole_groups = sp >= round_up((size_t)W, 4) * 3;
+  if (c->per_channel && !whole_groups) return fail(HC_E_ARG, "per-channel mode needs an input pitch of at least 3 * round_up(width, 4) bytes");
+  const bool fuse_bgr = c->C == 3 && stage == HC_STAGE_HYSTER && whole_groups;
   if (c->C == 3 && !fuse_bgr) {
     if (stage == HC_STAGE_MONO) {
       HIPCK(launch_gray(src, sp, sfs, dst, dp, dfs, W, H, n, sf));
@@ -280,10 +286,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
 
   if (stage == HC_STAGE_HYSTER) {
     FrontParams fp{};
-    fp.in = mono; fp.bgr = fuse_bgr ? 1 : 0; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = s.d_sbits; fp.cbits = s.d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
+    fp.in = mono; fp.bgr = c->per_channel ? 2 : fuse_bgr ? 1 : 0; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = s.d_sbits; fp.cbits = s.d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
     const int chunk = c->chunk ? c->chunk : 16;
-    fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n;
-    fp.total_items = n * fp.nstrips * fp.nchunks;
+    fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n_out;
+    fp.total_items = n_out * fp.nstrips * fp.nchunks;
     band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);
     band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
     fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
@@ -295,7 +301,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       HIPCK(hipStreamWaitEvent(sh, s.ev_front, 0));
     }
     HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * FLAG_WORDS, sh));
-    if (int rc = queue_hyst_expand(c, s, sh, dst, dp, dfs, n, piped && !getenv("HC_PIPE_BIG_TILES"))) return rc;
+    if (int rc = queue_hyst_expand(c, s, sh, dst, dp, dfs, n_out, piped)) return rc;
   } else if (stage > HC_STAGE_MONO) {
     if (int rc = ensure_stage_scratch(c)) return rc;
     const size_t bp = c->out_pitch, bfs = c->out_fs;  // scratch planes share the output geometry
@@ -316,13 +322,13 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   } else if (prof) HIPCK(hipEventRecord(ev[2], sf));
 
   if (out_internal) {
-    if (int rc = copy_frames_d2d(c, sh, out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)W, n)) return rc;
+    if (int rc = copy_frames_d2d(c, sh, out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)W, n_out)) return rc;
     if (s.pending) { s.copy_dst = out; s.copy_pitch = out_pitch; s.copy_fs = out_fs; }
   }
   if (prof) { HIPCK(hipEventRecord(ev[3], sh)); c->ev_count++; }
   if (stage == HC_STAGE_HYSTER) HIPCK(hipEventRecord(s.ev_done, sh));
   if (piped) c->cur ^= 1;
-  c->last_run_n = n;
+  c->last_run_n = n_out;
   return HC_OK;
 }
 
@@ -440,7 +446,22 @@ int hc_set_option(hc_ctx *c, int option, int value)
   if (!c) return fail(HC_E_ARG, "null context");
   if (int rc = finish_all(c)) return rc;
   if (option == HC_OPT_NMS_SATURATE) c->nms_saturate = value != 0;
-  else if (option == HC_OPT_PIPELINE) {
+  else if (option == HC_OPT_PER_CHANNEL) {
+    if (c->C != 3) return fail(HC_E_ARG, "HC_OPT_PER_CHANNEL needs a 3-channel context");
+    if ((value != 0) != (c->per_channel != 0)) {  // output-side buffers change size: 3 edge maps per input frame
+      HIPCK(hipSetDevice(c->device));
+      HIPCK(hipDeviceSynchronize());
+      const bool had1 = c->slot[1].d_sbits != nullptr;
+      free_slot(c->slot[0]);
+      free_slot(c->slot[1]);
+      (void)hipFree(c->d_out);
+      c->d_out = nullptr;
+      c->per_channel = value != 0;
+      if (alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)c->W, c->H, c->max_batch * (c->per_channel ? 3 : 1)) != HC_OK) return HC_E_HIP;
+      if (alloc_slot(c, c->slot[0]) != HC_OK) return HC_E_HIP;
+      if (had1 && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;
+    }
+  } else if (option == HC_OPT_PIPELINE) {
     HIPCK(hipSetDevice(c->device));
     if (value && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;
     c->pipeline = value != 0;

@@ -119,8 +119,13 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * run i+1 (own stream) overlaps the hysteresis + expand of run i (second stream, second set of bit
  * planes).  The context stream still orders each run after the caller's earlier work and is held
  * until the run's input has been consumed; the OUTPUT of a run is only guaranteed after hc_sync()
- * (or hc_download).  Results are identical in both modes. */
-enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2 };
+ * (or hc_download).  Results are identical in both modes.
+ *
+ * HC_OPT_PER_CHANNEL (default 0, 3-channel contexts only): 1 = instead of the reference's grey
+ * conversion, run the detector on each channel separately (BASELINE config "three-channel,
+ * per-channel Canny"): the interleaved input is read once per channel by adjacent work items and
+ * every run produces 3 edge maps per input frame, output frame 3*f + ch (ch = byte position in the pixel). */
+enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* Device self-test of the cross-lane / packed-math primitives the kernels rely on. 0 = ok. */

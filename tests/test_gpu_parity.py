@@ -96,6 +96,25 @@ def test_bgr_fused_and_fallback(oracle):
                 _diff(d_out[f].cpu().numpy(), want[f], f"bgr run_device {w}x{h} frame {f}")
 
 
+def test_per_channel_mode(oracle):
+    """HC_OPT_PER_CHANNEL: three edge maps per interleaved 3-channel frame (BASELINE config C5 at a
+    small size), each equal to the detector run on that channel alone."""
+    rng = np.random.default_rng(21)
+    w, h = 501, 77
+    img = np.stack([np.stack([synth.natural(w, h, 60 + 3 * f + c) for c in range(3)], axis=2) for f in range(2)])
+    img[1, 10:40, 100:300, 2] = rng.integers(0, 256, (30, 200), dtype=np.uint8)
+    with api.Context(w, h, 3, 2) as ctx:
+        ctx.set_option(api.OPT_PER_CHANNEL, 1)
+        ctx.upload(img)
+        ctx.run(api.CannyStage.HYSTER, 2)
+        got = ctx.download(6)
+        for f in range(2):
+            for c in range(3):
+                _diff(got[3 * f + c], oracle.canny_r(np.ascontiguousarray(img[f, :, :, c]), 10, 40), f"per-channel frame {f} ch {c}")
+        ctx.set_option(api.OPT_PER_CHANNEL, 0)
+        _diff(ctx.process(img)[1], oracle.canny_r(img[1], 10, 40), "grey mode after per-channel mode")
+
+
 @pytest.mark.parametrize("low,high", [(0, 0), (0, 255), (255, 255), (5, 250), (40, 10), (100, 101)])
 def test_thresholds(oracle, low, high):
     img = synth.steps(300, 200, 250, "diagonal")
