@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 from cudacam_amd import api, shard, synth  # noqa: E402
 
-W, H = 1920, 1080
+W, H = 1920, 1080          # configs[1]; --width/--height select another BASELINE config (e.g. 3840x2160)
 LOW, HIGH = 10, 40
 HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_MEASURED_COPY_GBPS = 6290.0
@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--hyst-launches", type=int, default=4)
     ap.add_argument("--pipeline", action="store_true", help="HC_OPT_PIPELINE: overlap run i+1's front kernel with run i's hysteresis (measured: no gain, both kernels compete for the same CUs)")
+    ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU baseline sample (0 = auto)")
     return ap.parse_args()
@@ -49,6 +52,10 @@ def parse():
 
 def main():
     a = parse()
+    global W, H, LOW, HIGH
+    W, H = a.width, a.height
+    if a.mode == "O":
+        LOW, HIGH = 50, 150
     api.preload_hip_runtime()
     import torch
     import torch.distributed as dist
@@ -74,7 +81,7 @@ def main():
     d_out = torch.empty_like(d_in)
     del d_u
 
-    ctx = api.Context(W, H, 1, B, api.MODE_R, device=local)
+    ctx = api.Context(W, H, 1, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local)
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
     ctx.set_option(api.OPT_PIPELINE, 1 if a.pipeline else 0)
@@ -115,7 +122,7 @@ def main():
         hyst_ms = sums[2] / max(nruns, 1)
         achieved = alg_bytes_per_launch / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
         out = {
-            "metric": "frames/sec, 1080p grayscale Canny (5-stage, Mode R, device-resident)",
+            "metric": f"frames/sec, {W}x{H} grayscale Canny (" + ("5-stage, Mode R" if a.mode == "R" else "cv::Canny semantics, Mode O") + ", device-resident)",
             "value": round(fps, 1),
             "unit": "frames/s",
             "n_gpus": world,
@@ -128,12 +135,13 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": f"synthetic ({a.kind}, {min(a.unique, B)} distinct frames tiled to the batch)",
-            "config": {"workload": f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU",
+            "config": {"workload": (f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU" if (W, H, a.mode) == (1920, 1080, "R")
+                                    else f"{W}x{H} grayscale, mode {a.mode}, batch {B} frames/step/GPU"),
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",
                        "pipeline": bool(a.pipeline)},
             "e2e_alg_GBps": round(2.0 * W * H * frames_total / elapsed / 1e9, 1),
             "roofline": {
-                "bound": "hbm", "kernel": "k_front", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": "k_front" if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(achieved / HBM_MEASURED_COPY_GBPS, 4),
                 "traffic": None, "kernel_ms": round(front_ms, 4), "hyst_expand_ms": round(hyst_ms, 4), "launches_timed": nruns,
             },
@@ -158,13 +166,14 @@ def cpu_baseline(a, d_in, d_out):
     n = a.cpu_frames or max(cores * 4, 16)
     n = min(n, d_in.shape[0])
     sample = d_in[:n].cpu().numpy()
-    O.canny_r_batch(sample[:min(n, cores)], LOW, HIGH, threads=cores)   # warm the pages/threads
+    run = O.canny_r_batch if a.mode == "R" else O.canny_o_batch
+    run(sample[:min(n, cores)], LOW, HIGH, threads=cores)   # warm the pages/threads
     t0 = time.perf_counter()
-    ref = O.canny_r_batch(sample, LOW, HIGH, threads=cores)
+    ref = run(sample, LOW, HIGH, threads=cores)
     dt = time.perf_counter() - t0
     same = bool(np.array_equal(ref, d_out[:n].cpu().numpy()))
     return {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of the benchmark's 1080p frames, OpenMP over frames, oracle/canny_oracle.c",
+            "sample": f"{n} of the benchmark's {W}x{H} frames, OpenMP over frames, oracle/canny_oracle.c ({'orc_canny_r' if a.mode == 'R' else 'orc_canny_o'})",
             "gpu_output_matches": same}
 
 

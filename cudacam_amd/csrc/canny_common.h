@@ -31,6 +31,7 @@ struct FrontParams {
   int RD;                  // dwords per bit-plane row
   int W, H;
   int nstrips, nchunks, nframes;
+  int chunk_rows;          // Mode O kernel: output rows per work item (any value >= 1)
   int total_items;         // nframes * nstrips * nchunks
   // thresholds on S = sumX^2 + sumY^2 for "u8-wrapped gradient > T" (band test)
   u32 a_lo[3], a_hi[3];
@@ -76,6 +77,7 @@ struct PackParams {  // tri-state u8 map (0/128/255) -> bit planes
 hipError_t launch_selftest(u32 *d_result, hipStream_t s);
 hipError_t upload_gauss_coeffs(const float gk[25]);
 hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s);
+hipError_t launch_front_o(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 hipError_t launch_expand(const ExpandParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);

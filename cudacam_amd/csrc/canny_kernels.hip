@@ -480,6 +480,172 @@ hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s)
 }
 
 // =================================================================================================
+// k_front_o: "Mode O" -- cv::Canny(src 8UC1, low, high, apertureSize 3, L2gradient false) semantics
+// =================================================================================================
+// OpenCV 4.x modules/imgproc/src/canny.cpp as restated in oracle/canny_oracle.c (orc_canny_o): no blur,
+// Sobel 3x3 on the source with BORDER_REPLICATE, L1 magnitude m = |dx|+|dy| (0 outside the image),
+// pixels with m <= low are dropped, direction by the integer tangent test (TG22 = 13573, shift 15),
+// asymmetric non-maximum suppression (m > first neighbour, m >= second on the axes; strict on both
+// diagonal neighbours), m > high seeds.  Same strip / lane / DPP layout and the same bit-plane
+// output as k_front, so k_hyst finishes the job.  One pass, registers only (no LDS): a work item is
+// (frame, strip, chunk of p.chunk_rows rows) with a 4-row warm-up.
+__global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
+{
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
+  if (item >= p.total_items) return;
+  const int chunk = item % p.nchunks;
+  const int strip = (item / p.nchunks) % p.nstrips;
+  const int frame = item / (p.nchunks * p.nstrips);
+  const int W = p.W, H = p.H, CH = p.chunk_rows;
+  const int r0 = chunk * CH, rend = min(r0 + CH, H);
+  const int c0 = strip * STRIP_W - STRIP_HALO + lane * PX_PER_LANE;
+
+  // BORDER_REPLICATE along the row: the 4 columns of this lane, clamped into the image, always lie in
+  // one aligned dword; a per-lane byte selector arranges (and repeats) them
+  u32 cmask = 0, rsel = 0;
+  const int cl0 = min(max(c0, 0), W - 1);
+  const int ld_col = cl0 & ~3;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool in = (c0 + k >= 0) && (c0 + k < W);
+    cmask |= in ? (0xFFu << (8 * k)) : 0u;
+    const int cc = min(max(c0 + k, 0), W - 1);
+    rsel |= (u32)(cc - ld_col) << (8 * k);  // 0..3: byte of the loaded dword (cc - ld_col < 4 by construction)
+  }
+  const u32 pm0 = __builtin_amdgcn_perm(0u, cmask, 0x01010000u), pm1 = __builtin_amdgcn_perm(0u, cmask, 0x03030202u);
+  const u32 oknib1 = (lane >= 1 && lane <= 62) ? ((cmask & 1u) | ((cmask >> 7) & 2u) | ((cmask >> 14) & 4u) | ((cmask >> 21) & 8u)) : 0u;
+  const u32 oknib = oknib1 | (oknib1 << 8);
+  const uint8_t *src = p.in + (size_t)frame * p.in_frame_stride + ld_col;
+  auto load_row = [&](int row) -> u32 {  // BORDER_REPLICATE along the column: clamp the row
+    const int rr = min(max(row, 0), H - 1);
+    return __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32 *>(src + (size_t)rr * p.in_pitch), rsel);
+  };
+
+  u32 dr[2][2], sr[2][2];  // d = x[+1]-x[-1] and s = x[-1]+2x[0]+x[+1] of the two previous rows, [ring][pair]
+  u32 Mr[3][6];            // magnitude rows: [ring][0]=left neighbour, [1..4]=own 4 px, [5]=right neighbour
+  u32 Vr[2][4];            // packed (dx,dy) of the two newest gradient rows
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) dr[a][b] = sr[a][b] = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) Mr[a][b] = 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) Vr[a][b] = 0;
+  const size_t plane_off = (size_t)frame * H * p.RD * 4 + (size_t)strip * 31 + (size_t)((lane - 1) >> 1);
+  uint8_t *srow = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
+  uint8_t *crow = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
+  const bool store_lane = (lane & 1) && lane < 63;
+  const u32 low = p.a_lo[0], high = p.a_hi[0];  // Mode O: plain thresholds on m
+
+  // step t: source row k = r0 - 2 + t arrives; gradient row i = k - 1; NMS row c = k - 2
+  const int nsteps = (rend - r0) + 4;
+  constexpr int G = 6;
+  u32 xn[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) xn[j] = load_row(r0 - 2 + j);
+#pragma nounroll
+  for (int t0 = 0; t0 < nsteps; t0 += G) {
+    u32 xc[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) xc[j] = xn[j];
+    if (t0 + G < nsteps)
+#pragma unroll
+      for (int j = 0; j < G; ++j) xn[j] = load_row(r0 - 2 + t0 + G + j);
+#pragma unroll
+    for (int u = 0; u < G; ++u) {
+      const int t = t0 + u;
+      if (t >= nsteps) break;
+      const int k = r0 - 2 + t;
+      const int rn = u % 2, rp = (u + 1) % 2;
+      const int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;
+      const u32 b = xc[u];
+      const u32 A = unpack_lo(b), B = unpack_hi(b);
+      const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
+      const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
+      u32 dk[2], sk[2];
+      dk[0] = R(I(p1) - I(m1));
+      sk[0] = pk_mad2(A, m1 + p1);
+      dk[1] = R(I(p3) - I(p1));
+      sk[1] = pk_mad2(B, p1 + p3);
+      const int i = k - 1;  // gradient row from source rows k-2 (ring rn), k-1 (ring rp), k (new)
+      if (i >= 0 && i < H) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const u32 pm = h == 0 ? pm0 : pm1;  // magnitude outside the image is 0
+          const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;  // dx = right - left, smoothed 1-2-1 down the rows
+          const u32 Y = R(I(sk[h]) - I(sr[rn][h])) & pm;                       // dy = bottom - top
+          Vr[rn][2 * h + 0] = __builtin_amdgcn_perm(Y, X, 0x05040100u);
+          Vr[rn][2 * h + 1] = __builtin_amdgcn_perm(Y, X, 0x07060302u);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const i16x2 v = I(Vr[rn][q]);
+          const u32 av = R(__builtin_elementwise_max(v, -v));                // (|dx|, |dy|)
+          Mr[sN][1 + q] = __builtin_amdgcn_udot2(U(av), U(0x00010001u), 0u, false);  // L1 magnitude
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { Mr[sN][1 + q] = 0; Vr[rn][q] = 0; }
+      }
+      Mr[sN][0] = from_lane_below(Mr[sN][4]);
+      Mr[sN][5] = from_lane_above(Mr[sN][1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
+
+      const int c = k - 2;
+      if (c >= r0 && c < rend) {
+        u32 nib = 0;
+        const u32 mx = max(max(Mr[sC][1], Mr[sC][2]), max(Mr[sC][3], Mr[sC][4]));
+        if (__ballot(mx > low) != 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32 m = Mr[sC][1 + q];
+            const u64 cl = __ballot(m > low), st = __ballot(m > high);
+            if (cl == 0) continue;
+            const u32 V = Vr[rp][q];
+            const i16x2 v = I(V);
+            const u32 av = R(__builtin_elementwise_max(v, -v));
+            const u32 x = av & 0xFFFFu, y = av >> 16;
+            const u32 tg22 = x * 13573u, ysh = y << 15;
+            const u32 tg67 = tg22 + (x << 16);
+            const u64 hz = __ballot(ysh < tg22), vt = __ballot(ysh > tg67);
+            const u64 dneg = __ballot((int)(V ^ (V << 16)) < 0);  // sign(dx) != sign(dy)
+            const u64 kh = __ballot(m > Mr[sC][q]) & __ballot(m >= Mr[sC][2 + q]);       // left, right
+            const u64 kv = __ballot(m > Mr[sU][1 + q]) & __ballot(m >= Mr[sN][1 + q]);   // up, down
+            const u64 kp = __ballot(m > Mr[sU][q]) & __ballot(m > Mr[sN][2 + q]);        // s = +1: up-left, down-right
+            const u64 kn = __ballot(m > Mr[sU][2 + q]) & __ballot(m > Mr[sN][q]);        // s = -1: up-right, down-left
+            const u64 dg = ~hz & ~vt;
+            const u64 keep = (hz & kh) | (~hz & vt & kv) | (dg & ~dneg & kp) | (dg & dneg & kn);
+            nib |= __builtin_amdgcn_inverse_ballot_w64(st & keep) ? (1u << q) : 0u;
+            nib |= __builtin_amdgcn_inverse_ballot_w64(cl & keep) ? (0x100u << q) : 0u;
+          }
+          nib &= oknib;
+        }
+        const u32 w = nib | (from_lane_above(nib) << 4);
+        if (store_lane) {
+          srow[(size_t)c * p.RD * 4] = (uint8_t)w;
+          crow[(size_t)c * p.RD * 4] = (uint8_t)(w >> 8);
+        }
+      }
+    }
+  }
+}
+
+hipError_t launch_front_o(const FrontParams &p, hipStream_t s)
+{
+  if (p.chunk_rows < 1 || p.bgr) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_front_o, dim3((p.total_items + 3) / 4), dim3(256), 0, s, p);
+  return hipGetLastError();
+}
+
+// =================================================================================================
 // k_pack: tri-state u8 map (0 / 128 / 255) -> bit planes (entry of hc_hysteresis_device)
 // =================================================================================================
 __global__ __launch_bounds__(256) void k_pack(const PackParams p)

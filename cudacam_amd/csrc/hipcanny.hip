@@ -231,7 +231,8 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
 
 int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_t *out, size_t out_pitch, size_t out_fs, int n, int stage)
 {
-  if (c->mode != HC_MODE_R) return fail(HC_E_ARG, "mode O is not built into this library version");
+  if (c->mode == HC_MODE_O && (c->C != 1 || stage != HC_STAGE_HYSTER))
+    return fail(HC_E_ARG, "mode O (cv::Canny) is implemented for 1-channel input and the final edge map only");
   if (c->per_channel && stage != HC_STAGE_HYSTER) return fail(HC_E_ARG, "per-channel mode only produces the final edge maps (HC_STAGE_HYSTER)");
   const int W = c->W, H = c->H;
   const int n_out = c->per_channel ? 3 * n : n;  // output frames (= bit-plane frames)
@@ -290,10 +291,22 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     const int chunk = c->chunk ? c->chunk : 16;
     fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n_out;
     fp.total_items = n_out * fp.nstrips * fp.nchunks;
-    band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);
-    band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
-    fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
-    HIPCK(launch_front(fp, chunk, sf));
+    if (c->mode == HC_MODE_O) {
+      // cv::Canny: plain thresholds on the L1 magnitude; long chunks (no LDS slab, 4-row warm-up)
+      fp.a_lo[0] = (u32)c->low; fp.a_hi[0] = (u32)c->high;
+      const long units = (long)n_out * c->nstrips;
+      const int per_strip = (int)std::max<long>(1, std::min<long>((12288 + units - 1) / units, (H + 15) / 16));
+      fp.chunk_rows = (H + per_strip - 1) / per_strip;
+      fp.nchunks = (H + fp.chunk_rows - 1) / fp.chunk_rows;
+      fp.total_items = n_out * fp.nstrips * fp.nchunks;
+      if (sp < round_up((size_t)W, 4)) return fail(HC_E_ARG, "mode O needs an input pitch of at least round_up(width, 4)");
+      HIPCK(launch_front_o(fp, sf));
+    } else {
+      band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);
+      band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
+      fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
+      HIPCK(launch_front(fp, chunk, sf));
+    }
     if (prof) HIPCK(hipEventRecord(ev[2], sf));
     if (piped) {
       HIPCK(hipEventRecord(s.ev_front, sf));
@@ -408,8 +421,9 @@ void hc_destroy(hc_ctx *c)
 int hc_set_thresholds(hc_ctx *c, int low, int high)
 {
   if (!c) return fail(HC_E_ARG, "null context");
-  low = std::max(0, std::min(255, low));
-  high = std::max(0, std::min(255, high));
+  const int tmax = c->mode == HC_MODE_O ? 32767 : 255;  // Mode O thresholds apply to |dx|+|dy| (up to 2040)
+  low = std::max(0, std::min(tmax, low));
+  high = std::max(0, std::min(tmax, high));
   if (low > high) std::swap(low, high);
   c->low = low; c->high = high;
   return HC_OK;

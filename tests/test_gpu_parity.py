@@ -215,6 +215,35 @@ def test_run_device_unaligned_and_torch_stream(oracle):
         _diff(d_out.cpu().numpy(), want, "unaligned run_device")
 
 
+MODE_O_IMAGES = [
+    ("natural_640x480", lambda: synth.natural(640, 480, 1), 50, 150),
+    ("noise_641x479", lambda: synth.noise(641, 479, 2), 100, 300),
+    ("noise_low_thresholds", lambda: synth.noise(333, 222, 5), 0, 40),
+    ("natural_31x33", lambda: synth.natural(31, 33, 3), 20, 60),
+    ("one_px", lambda: np.array([[200]], np.uint8), 50, 150),
+    ("five", lambda: synth.noise(5, 5, 4), 10, 30),
+    ("flat255", lambda: synth.flat(300, 70, 255), 50, 150),
+    ("step_v", lambda: synth.steps(260, 64, 255, "vertical"), 50, 150),
+    ("step_d", lambda: synth.steps(250, 250, 120, "diagonal"), 50, 150),
+    ("serpentine", lambda: synth.serpentine(500, 300, amp=30, seed_amp=200), 50, 150),
+    ("natural_1080p", lambda: synth.natural(1920, 1080, 9), 50, 150),
+    ("natural_4k_strip", lambda: synth.natural(3840, 100, 10), 30, 90),
+    ("swapped_thresholds", lambda: synth.natural(200, 100, 8), 150, 50),
+]
+
+
+@pytest.mark.parametrize("name,make,low,high", MODE_O_IMAGES, ids=[m[0] for m in MODE_O_IMAGES])
+def test_mode_o_matches_cv_canny_restatement(oracle, name, make, low, high):
+    """Mode O: the HIP path against the oracle's restatement of cv::Canny(img, low, high, 3, false)
+    (OpenCV itself is not installed anywhere in this pipeline: parity with the real library is unpinned)."""
+    img = make()
+    h, w = img.shape
+    want = oracle.canny_o(img, low, high)
+    with api.Context(w, h, 1, 1, api.MODE_O) as ctx:
+        ctx.set_thresholds(low, high)
+        _diff(ctx.process(img)[0], want, f"mode O {name}")
+
+
 def test_pipelined_runs(oracle):
     """HC_OPT_PIPELINE: back-to-back device runs overlap (front of run i+1 / hysteresis of run i);
     every run's output must still be exactly the oracle's after hc_sync."""
