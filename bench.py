@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--hyst-launches", type=int, default=4)
+    ap.add_argument("--hyst-launches", type=int, default=6)
     ap.add_argument("--pipeline", action="store_true", help="HC_OPT_PIPELINE: overlap run i+1's front kernel with run i's hysteresis (measured: no gain, both kernels compete for the same CUs)")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
     ap.add_argument("--width", type=int, default=1920)
