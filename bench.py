@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--hyst-launches", type=int, default=6)
-    ap.add_argument("--pipeline", action="store_true", help="HC_OPT_PIPELINE: overlap run i+1's front kernel with run i's hysteresis (measured: no gain, both kernels compete for the same CUs)")
+    ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -84,7 +84,7 @@ def main():
     ctx = api.Context(W, H, 1, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local)
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
-    ctx.set_option(api.OPT_PIPELINE, 1 if a.pipeline else 0)
+    ctx.set_option(api.OPT_PIPELINE, 0 if a.no_pipeline else 1)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -138,7 +138,7 @@ def main():
             "config": {"workload": (f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU" if (W, H, a.mode) == (1920, 1080, "R")
                                     else f"{W}x{H} grayscale, mode {a.mode}, batch {B} frames/step/GPU"),
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",
-                       "pipeline": bool(a.pipeline)},
+                       "pipeline": not a.no_pipeline},
             "e2e_alg_GBps": round(2.0 * W * H * frames_total / elapsed / 1e9, 1),
             "roofline": {
                 "bound": "hbm", "kernel": "k_front" if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

@@ -448,7 +448,7 @@ int hc_set_stream(hc_ctx *c, void *s)
 int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
 {
   if (!c) return fail(HC_E_ARG, "null context");
-  if (chunk_rows != 0 && chunk_rows != 8 && chunk_rows != 16 && chunk_rows != 32 && chunk_rows != 64) return fail(HC_E_ARG, "chunk_rows must be 0, 8, 16, 32 or 64");
+  if (chunk_rows != 0 && chunk_rows != 8 && chunk_rows != 16 && chunk_rows != 20 && chunk_rows != 24 && chunk_rows != 32 && chunk_rows != 64) return fail(HC_E_ARG, "chunk_rows must be 0, 8, 16, 20, 24, 32 or 64");
   if (hyst_launches < 1 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range");
   if (int rc = finish_all(c)) return rc;
   c->chunk = chunk_rows; c->hyst_launches = hyst_launches;
