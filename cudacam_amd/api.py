@@ -15,7 +15,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhipcanny.so")
+LIB_PATH = os.environ.get("HIPCANNY_LIB") or os.path.join(_HERE, "libhipcanny.so")  # override: kernel experiments only
 
 
 class CannyStage(enum.IntEnum):

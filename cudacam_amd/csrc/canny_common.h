@@ -31,6 +31,8 @@ struct FrontParams {
   int RD;                  // dwords per bit-plane row
   int W, H;
   int nstrips, nchunks, nframes;
+  int subchunks;   // Mode R kernel: sub-chunks of 24 blur rows a wave marches through per work item
+  int run_rows;    // = 24 * subchunks - 4 output rows per work item; nchunks = ceil(H / run_rows)
   int chunk_rows;          // Mode O kernel: output rows per work item (any value >= 1)
   int total_items;         // nframes * nstrips * nchunks
   // thresholds on S = sumX^2 + sumY^2 for "u8-wrapped gradient > T" (band test)
@@ -76,12 +78,13 @@ struct PackParams {  // tri-state u8 map (0/128/255) -> bit planes
 // ---- host-callable launchers (defined in canny_kernels.hip) -----------------------------------
 hipError_t launch_selftest(u32 *d_result, hipStream_t s);
 hipError_t upload_gauss_coeffs(const float gk[25]);
-hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s);
+hipError_t launch_front(const FrontParams &p, hipStream_t s);
 hipError_t launch_front_o(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 hipError_t launch_expand(const ExpandParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
-size_t front_lds_bytes(int chunk_rows);
+size_t front_lds_bytes();
+int front_run_rows(int subchunks);
 void hyst_tile_geometry(int RD, int *tile_rows, int *waves);
 
 // plain per-stage kernels (exact, unfused): the `finalStage` taps MONO..THRESH of CannyEdge::run

@@ -24,7 +24,24 @@ typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 __constant__ float c_gk[25];  // reference: __constant__ float GK[5][5], cannyEdgeD.cu:11
 
-hipError_t upload_gauss_coeffs(const float gk[25]) { return hipMemcpyToSymbol(HIP_SYMBOL(c_gk), gk, 25 * sizeof(float)); }
+// The same 25 values as compile-time constants: K * (1 / 159.0f), both roundings in binary32 (constant
+// folding is IEEE round-to-nearest).  upload_gauss_coeffs() refuses a host table that differs.
+struct GaussLiterals {
+  float v[25];
+  constexpr GaussLiterals() : v{}
+  {
+    constexpr int K[25] = { 2, 4, 5, 4, 2, 4, 9, 12, 9, 4, 5, 12, 15, 12, 5, 4, 9, 12, 9, 4, 2, 4, 5, 4, 2 };
+    constexpr float r = 1.0f / 159.0f;
+    for (int i = 0; i < 25; ++i) v[i] = (float)K[i] * r;
+  }
+};
+constexpr GaussLiterals GKC{};
+
+hipError_t upload_gauss_coeffs(const float gk[25])
+{
+  if (memcmp(gk, GKC.v, sizeof(GKC.v)) != 0) return hipErrorInvalidValue;  // the fused kernel's literals would disagree
+  return hipMemcpyToSymbol(HIP_SYMBOL(c_gk), gk, 25 * sizeof(float));
+}
 
 // ---- cross-lane and packed helpers -------------------------------------------------------------
 // value held by lane-1 (0 in lane 0) / lane+1 (0 in lane 63): DPP wave shifts, no LDS involved
@@ -44,6 +61,13 @@ static __device__ __forceinline__ u32 R(i16x2 v) { return __builtin_bit_cast(u32
 static __device__ __forceinline__ u32 pk_mad2(u32 a, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c)); return d; }
 static __device__ __forceinline__ u32 pk_mul5(u32 a) { u32 d; asm("v_pk_mul_lo_u16 %0, %1, 5 op_sel_hi:[1,0]" : "=v"(d) : "v"(a)); return d; }
 static __device__ __forceinline__ int sdot2_0(u32 a, u32 b) { int d; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d; }
+// v*2 + (bit of `mask` for this lane): shifts one ballot mask into per-lane words (carry-in form of v_addc)
+static __device__ __forceinline__ u32 shift_in(u32 v, u64 mask)
+{
+  u32 d; u64 co;
+  asm("v_addc_co_u32_e64 %0, %1, %2, %2, %3" : "=v"(d), "=s"(co) : "v"(v), "s"(mask));
+  return d;
+}
 static __device__ __forceinline__ void wave_lds_sync()
 {
   // wave-private LDS hand-off between lanes of ONE wave: DS ops of a wave execute in order, this
@@ -91,6 +115,7 @@ __global__ void k_selftest(u32 *res)
   const u64 m = __ballot(lane & 1);
   bad |= (m != 0xAAAAAAAAAAAAAAAAull) ? 1024u : 0u;
   bad |= (mbcnt64(m) != lane / 2) ? 2048u : 0u;
+  bad |= (shift_in(lane, m) != 2 * lane + (lane & 1)) ? 4096u : 0u;
   if (bad) atomicOr(res, bad);
 }
 
@@ -103,21 +128,22 @@ hipError_t launch_selftest(u32 *d_result, hipStream_t s)
 // =================================================================================================
 // k_front
 // =================================================================================================
-// Work item = (frame, strip, chunk of CHUNK output rows), one per wave, 4 independent waves per
-// workgroup (no workgroup barrier anywhere).  Two phases per item, both marching down the rows with
-// every intermediate in registers and horizontal neighbours fetched from the adjacent lane by DPP:
-//   phase 1  input rows -> blur rows (u8) into a wave-private LDS slab of CHUNK+4 rows
-//   fix-up   the few pixels whose exact float result cannot be decided by integers (see gauss_row)
-//   phase 2  blur rows -> Sobel -> S = sumX^2+sumY^2 -> direction -> NMS -> thresholds -> bit planes
-constexpr int QCAP = 248;   // fix-up queue entries (u16) per wave (expected fill: 0.6 % of the slab pixels)
+// Work item = (frame, strip, run of RUN = FSUB*m - 4 output rows), one per wave, 4 independent waves
+// per workgroup (no workgroup barrier anywhere).  A wave marches down its run in sub-chunks of FSUB
+// blur rows; every intermediate stays in registers (horizontal neighbours come from the adjacent lane
+// by DPP) except the blur rows of the current sub-chunk, which pass through a wave-private LDS slab:
+//   phase 1  FSUB input rows -> FSUB blur rows (u8) into the slab
+//   fix-up   the few pixels whose exact float result cannot be decided by integers (see below)
+//   phase 2  FSUB blur rows -> Sobel -> S = sumX^2+sumY^2 -> direction -> NMS -> thresholds -> bit planes
+// The vertical accumulators of phase 1 and the row rings of phase 2 are carried across sub-chunks, so
+// the only redundant work per run is the 4-row blur warm-up and the 4 extra blur rows (RUN+8 input
+// rows and RUN+4 blur rows per RUN output rows), while LDS stays at 6.5 KiB per wave.
+constexpr int FSUB = 24;    // blur rows per sub-chunk: multiple of the prefetch group (4) and of the ring period (6)
+constexpr int QCAP = 128;   // fix-up queue entries per wave and sub-chunk (one lane-dword each; expected fill ~37)
+constexpr int FRONT_WAVE_BYTES = FSUB * 256 + QCAP * 4;
 
-template <int CHUNK>
-struct FrontLds {
-  static constexpr int BROWS = CHUNK + 4;
-  static constexpr int WAVE_BYTES = BROWS * 256 + QCAP * 2 + 16;
-};
-
-size_t front_lds_bytes(int chunk_rows) { return (size_t)4 * ((chunk_rows + 4) * 256 + QCAP * 2 + 16); }
+size_t front_lds_bytes() { return (size_t)4 * FRONT_WAVE_BYTES; }  // 26,624 B: 6 workgroups per CU
+int front_run_rows(int subchunks) { return FSUB * subchunks - 4; }
 
 // literal reference chain for one pixel (cannyEdgeD.cu:102-115): 25 fused multiply-adds from 0.0f in
 // r-major / c-minor order, truncation.  Only used for the rare undecidable pixels.
@@ -125,6 +151,8 @@ size_t front_lds_bytes(int chunk_rows) { return (size_t)4 * ((chunk_rows + 4) * 
 template <int IN = 0>
 static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_t pitch, int W, int H, int row, int col, int ch = 0)
 {
+  // the coefficients are literals of the instruction stream (GKC): as __constant__ loads they were
+  // hoisted to the kernel entry and pinned 25 SGPRs across the hot loops
   float f = 0.0f;
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
@@ -140,21 +168,23 @@ static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_
         } else if (IN == 2) px = (float)frame[(size_t)rr * pitch + 3 * (size_t)cc + ch];
         else px = (float)frame[(size_t)rr * pitch + cc];
       }
-      f = __builtin_fmaf(c_gk[r * 5 + c], px, f);
+      f = __builtin_fmaf(GKC.v[r * 5 + c], px, f);
     }
   }
   return (u32)(int)f;
 }
 
-template <int CHUNK, int IN>
-__global__ __launch_bounds__(256) void k_front(const FrontParams p)
+#ifndef HC_FRONT_WAVES
+#define HC_FRONT_WAVES 4
+#endif
+template <int IN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HC_FRONT_WAVES, 8))) void k_front(const FrontParams p)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  unsigned char *blur_s = smem + wib * FrontLds<CHUNK>::WAVE_BYTES;
-  unsigned short *queue = reinterpret_cast<unsigned short *>(blur_s + FrontLds<CHUNK>::BROWS * 256);
-  u32 *qcount = reinterpret_cast<u32 *>(queue + QCAP);  // queue fill (may run past QCAP: overflow)
+  unsigned char *blur_s = smem + wib * FRONT_WAVE_BYTES;
+  u32 *queue = reinterpret_cast<u32 *>(blur_s + FSUB * 256);
 
   const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
   if (item >= p.total_items) return;
@@ -164,22 +194,18 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   const int frame = item / (p.nchunks * p.nstrips);           // output frame = bit-plane index
   const int in_frame = IN == 2 ? frame / 3 : frame, ch = IN == 2 ? frame % 3 : 0;
   const int W = p.W, H = p.H;
-  const int r0 = chunk * CHUNK;
+  const int r0 = chunk * p.run_rows;              // output rows [r0, rend)
+  const int rend = min(r0 + p.run_rows, H);
   const int c0 = strip * STRIP_W - STRIP_HALO + lane * PX_PER_LANE;
 
   // per-lane column validity: byte mask for packed u8 rows, dword masks for the 4 S values
   u32 cmask = 0;
-  u32 vm[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const bool in = (c0 + k >= 0) && (c0 + k < W);
-    vm[k] = in ? 0xFFFFFFFFu : 0u;
     cmask |= in ? (0xFFu << (8 * k)) : 0u;
   }
-  // packed-u16 "invalid pixel" masks: OR-ed into the division remainders so that pixels outside
-  // the image never look undecidable
-  const u32 inv0 = (vm[0] ? 0u : 0xFFFFu) | (vm[1] ? 0u : 0xFFFF0000u);
-  const u32 inv1 = (vm[2] ? 0u : 0xFFFFu) | (vm[3] ? 0u : 0xFFFF0000u);
+  const u32 hmask = cmask & 0x80808080u;  // "undecidable" flag positions of the pixels inside the image
   // packed-i16 masks (0xFFFF per in-image pixel) for the Sobel pairs, kept as plain VGPR values
   const u32 pm0 = __builtin_amdgcn_perm(0u, cmask, 0x01010000u), pm1 = __builtin_amdgcn_perm(0u, cmask, 0x03030202u);
   // nibble of pixel slots this lane may set in the bit planes (lanes 1..62, columns inside the image)
@@ -187,10 +213,38 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   const u32 oknib = oknib1 | (oknib1 << 8);
   const bool col_any = cmask != 0;
   const uint8_t *frame_base = p.in + (size_t)in_frame * p.in_frame_stride;
-  const uint8_t *src = frame_base + (IN ? 3 : 1) * c0;  // dereferenced only where col_any
+  const u32 plane_pitch = (u32)p.RD * 4u, in_pitch32 = (u32)p.in_pitch;  // launch_front checks H * pitch < 2^32
+  const u32 ld_off = (u32)((IN ? 3 : 1) * c0);          // used only where col_any (then c0 >= 0): uniform row base + 32-bit lane offset
   // per-channel mode: byte selectors that pull channel ch of 4 pixels out of 12 interleaved bytes
   const u32 selA = ch == 0 ? 0x0c060300u : ch == 1 ? 0x0c070401u : 0x0c0c0502u;  // from {d1,d0}: bytes ch, ch+3, (ch+6 if < 8)
   const u32 selB = ch == 0 ? 0x05020100u : ch == 1 ? 0x06020100u : 0x07040100u;  // from {d2,t}: t.b0, t.b1, (t.b2 | d2 byte), d2 byte
+
+  auto load_row = [&](int row) -> u32 {
+    u32 v = 0;
+    if (row >= 0 && row < H && col_any) {
+      const uint8_t *rowp = frame_base + (u32)row * in_pitch32;     // wave-uniform: scalar row base + 32-bit lane offset
+      u32 lo = ld_off;
+      asm volatile("" : "+v"(lo));                                  // keeps the lane offset out of a hoisted 64-bit VGPR pointer
+      if (IN == 2) {
+        const u32 *q = reinterpret_cast<const u32 *>(rowp + lo);
+        const u32 t = __builtin_amdgcn_perm(q[1], q[0], selA);
+        v = __builtin_amdgcn_perm(q[2], t, selB);
+      } else if (IN == 1) {
+        // 4 interleaved BGR pixels = 12 bytes = 3 dwords; stage 0 (cannyEdgeD.cu:53-69) fused into the
+        // load: each pixel's 3 bytes are aligned into one dword and reduced by one v_dot4 with the
+        // weights (7, 38, 19, 0); sum of weights = 64, so the reference's min(255, .) never triggers
+        const u32 *q = reinterpret_cast<const u32 *>(rowp + lo);
+        const u32 d0 = q[0], d1 = q[1], d2 = q[2];
+        const u32 wts = 0x00132607u;
+        const u32 m0 = __builtin_amdgcn_udot4(d0, wts, 0u, false) >> 6;
+        const u32 m1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), wts, 0u, false) >> 6;
+        const u32 m2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), wts, 0u, false) >> 6;
+        const u32 m3 = __builtin_amdgcn_udot4(d2 >> 8, wts, 0u, false) >> 6;
+        v = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+      } else v = *reinterpret_cast<const u32 *>(rowp + lo);
+    }
+    return v;
+  };
 
   // ------------------------------------------------------------------ phase 1: blur rows -> LDS
   // Packed u16 arithmetic, two pixels per VALU op.  With K the 5x5 integer kernel (sum 159) and
@@ -202,42 +256,16 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
   // plus coefficient error) << 1/159, so trunc(chain) == floor(S/159) unless S % 159 == 0; those
   // pixels (0.6 % of random data) are queued and recomputed with the literal fmaf chain.
   u32 a1[2] = { 0, 0 }, a2[2] = { 0, 0 }, a3[2] = { 0, 0 }, a4[2] = { 0, 0 };
-  if (lane == 0) *qcount = 0;
-  wave_lds_sync();
+  int qn = 0;  // queue fill of the current sub-chunk (wave-uniform, lives in an SGPR; may run past QCAP: overflow)
 
-  auto load_row = [&](int row) -> u32 {
-    u32 v = 0;
-    if (row >= 0 && row < H && col_any) {
-      if (IN == 2) {
-        const u32 *q = reinterpret_cast<const u32 *>(src + (size_t)row * p.in_pitch);
-        const u32 t = __builtin_amdgcn_perm(q[1], q[0], selA);
-        v = __builtin_amdgcn_perm(q[2], t, selB);
-      } else if (IN == 1) {
-        // 4 interleaved BGR pixels = 12 bytes = 3 dwords; stage 0 (cannyEdgeD.cu:53-69) fused into the
-        // load: each pixel's 3 bytes are aligned into one dword and reduced by one v_dot4 with the
-        // weights (7, 38, 19, 0); sum of weights = 64, so the reference's min(255, .) never triggers
-        const u32 *q = reinterpret_cast<const u32 *>(src + (size_t)row * p.in_pitch);
-        const u32 d0 = q[0], d1 = q[1], d2 = q[2];
-        const u32 wts = 0x00132607u;
-        const u32 m0 = __builtin_amdgcn_udot4(d0, wts, 0u, false) >> 6;
-        const u32 m1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), wts, 0u, false) >> 6;
-        const u32 m2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), wts, 0u, false) >> 6;
-        const u32 m3 = __builtin_amdgcn_udot4(d2 >> 8, wts, 0u, false) >> 6;
-        v = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
-      } else v = *reinterpret_cast<const u32 *>(src + (size_t)row * p.in_pitch);
-    }
-    return v;
-  };
-
-
-  auto phase1_row = [&](int jr, u32 xraw) {
+  // one input row into the vertical accumulators; returns the two packed pairs of S for blur row (row - 2)
+  auto accumulate = [&](u32 xraw, u32 Sp[2]) {
     const u32 x = xraw & cmask;
     const u32 A = unpack_lo(x), B = unpack_hi(x);
     const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
     const u32 m1 = pair_shift(A, Bl);  // (x-1, x0)
     const u32 p1 = pair_shift(B, A);   // (x1, x2)
     const u32 p3 = pair_shift(Ar, B);  // (x3, x4)
-    u32 Sp[2];
     // NB: every packed u16 sum below stays < 2^16 per half (S <= 40545), so plain 32-bit adds and
     // subtractions act on both halves at once without carry/borrow between them -- and v_add_u32 /
     // v_sub_u32 issue at twice the rate of the v_pk_* forms on gfx950 (tools/valu_rate2.hip).
@@ -257,82 +285,40 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
       a2[h] = a1[h] + h1;
       a1[h] = h0;
     }
-    const int rb = jr - 2;  // blur row completed by this step
-    if (rb >= r0 - 2) {     // wave-uniform
-      const int slot = rb - (r0 - 2);
-      u32 bl = 0;
-      if (rb >= 0 && rb < H) {
-        // n = floor(S/159) = (S*52759) >> 23, exact for S <= 40545 (tests/test_oracle_exhaustive.py)
-        const u16x2 mlo = { 52759, 0 }, mhi = { 0, 52759 };
-        const u32 n0 = __builtin_amdgcn_udot2(U(Sp[0]), mlo, 0u, false) >> 23;
-        const u32 n1 = __builtin_amdgcn_udot2(U(Sp[0]), mhi, 0u, false) >> 23;
-        const u32 n2 = __builtin_amdgcn_udot2(U(Sp[1]), mlo, 0u, false) >> 23;
-        const u32 n3 = __builtin_amdgcn_udot2(U(Sp[1]), mhi, 0u, false) >> 23;
-        const u32 B0 = n0 | (n1 << 16), B1 = n2 | (n3 << 16);
-        const u16x2 c159 = { 159, 159 };
-        const u32 rem0 = (Sp[0] - R(U(B0) * c159)) | inv0, rem1 = (Sp[1] - R(U(B1) * c159)) | inv1;  // remainders >= 0: no borrow
-        bl = __builtin_amdgcn_perm(B1, B0, 0x06040200u) & cmask;
-        // undecidable pixels: remainder 0.  One cheap wave-wide test first.
-        const u16x2 z = __builtin_elementwise_min(U(rem0), U(rem1));
-        if (z.x == 0 || z.y == 0) {  // few lanes, if any: claim queue slots with an LDS counter
-          u32 fl = ((rem0 & 0xFFFFu) == 0 ? 1u : 0u) | ((rem0 >> 16) == 0 ? 2u : 0u) | ((rem1 & 0xFFFFu) == 0 ? 4u : 0u) | ((rem1 >> 16) == 0 ? 8u : 0u);
-          const u32 abase = (u32)slot * 256u + (u32)lane * 4u;
-          while (fl) {
-            const u32 k = (u32)__builtin_ctz(fl);
-            fl &= fl - 1;
-            const u32 idx = atomicAdd(qcount, 1u);
-            if (idx < (u32)QCAP) queue[idx] = (unsigned short)(abase + k);
-          }
-        }
-      }
-      reinterpret_cast<u32 *>(blur_s)[slot * 64 + lane] = bl;
-    }
   };
 
-  {
-    constexpr int G = 4;  // rows per prefetch group (CHUNK + 8 is a multiple of 4)
-    u32 xn[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) xn[j] = load_row(r0 - 4 + j);
-#pragma nounroll
-    for (int jr0 = r0 - 4; jr0 < r0 + CHUNK + 4; jr0 += G) {
-      u32 xc[G];
-#pragma unroll
-      for (int j = 0; j < G; ++j) xc[j] = xn[j];
-      if (jr0 + G < r0 + CHUNK + 4)
-#pragma unroll
-        for (int j = 0; j < G; ++j) xn[j] = load_row(jr0 + G + j);
-#pragma unroll
-      for (int j = 0; j < G; ++j) phase1_row(jr0 + j, xc[j]);
-    }
-  }
-  // fix-up: the queued pixels get the literal chain.  If the queue overflowed (large flat regions:
-  // every pixel of a constant area has S = 159*v), every pixel of the slab is recomputed instead.
-  wave_lds_sync();
-  const int qn = (int)__builtin_amdgcn_readfirstlane(*qcount);
-  if (qn <= QCAP) {
-#pragma nounroll
-    for (int base = 0; base < qn; base += 64) {
-      const int e = base + lane;
-      if (e < qn) {
-        const u32 a = queue[e];
-        const int row = r0 - 2 + (int)(a >> 8);
-        const int col = strip * STRIP_W - STRIP_HALO + (int)(a & 255u);
-        blur_s[a] = (unsigned char)gauss_chain_px<IN>(frame_base, p.in_pitch, W, H, row, col, ch);
+  // input row jr -> blur row rb = jr - 2 into slab slot `slot`
+  auto phase1_row = [&](int rb, int slot, u32 xraw) {
+    u32 Sp[2];
+    accumulate(xraw, Sp);
+    u32 bl = 0;
+    if (rb >= 0 && rb < H) {  // wave-uniform
+      // n = floor(S/159) = (S*52759) >> 23, exact for S <= 40545 (tests/test_oracle_exhaustive.py).
+      // S % 159 == 0  <=>  bits 15..22 of the product are all zero (the fraction is 73*n/2^23 < 2^-8 then
+      // and >= 52759/2^23 > 2^-8 otherwise): after >> 15 the low byte is that "fraction byte", the next is n.
+      const u16x2 mlo = { 52759, 0 }, mhi = { 0, 52759 };
+      const u32 t0 = __builtin_amdgcn_udot2(U(Sp[0]), mlo, 0u, false) >> 15;
+      const u32 t1 = __builtin_amdgcn_udot2(U(Sp[0]), mhi, 0u, false) >> 15;
+      const u32 t2 = __builtin_amdgcn_udot2(U(Sp[1]), mlo, 0u, false) >> 15;
+      const u32 t3 = __builtin_amdgcn_udot2(U(Sp[1]), mhi, 0u, false) >> 15;
+      const u32 nf01 = __builtin_amdgcn_perm(t1, t0, 0x04000501u);  // (n0, n1, f0, f1)
+      const u32 nf23 = __builtin_amdgcn_perm(t3, t2, 0x04000501u);
+      bl = __builtin_amdgcn_perm(nf23, nf01, 0x05040100u) & cmask;
+      const u32 fz = __builtin_amdgcn_perm(nf23, nf01, 0x07060302u);
+      // zero-byte detector: bit 7 of every byte that is 0 (a byte equal to 1 above a zero byte may be
+      // flagged too: harmless, the exact chain is then evaluated for a pixel that did not need it)
+      const u32 hz = (fz - 0x01010101u) & ~fz & hmask;
+      const u64 any = __ballot(hz != 0);
+      if (any != 0) {  // most rows have a pixel or two: one queue entry per flagged lane
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(any >> 32), __builtin_amdgcn_mbcnt_lo((u32)any, (u32)qn));
+        if (hz != 0 && rank < (u32)QCAP) queue[rank] = hz | (u32)lane | ((u32)slot << 8);
+        qn += __popcll(any);
       }
     }
-  } else {
-#pragma nounroll
-    for (int e = lane; e < FrontLds<CHUNK>::BROWS * 256; e += 64) {  // e = slot*256 + lane'*4 + k
-      const int row = r0 - 2 + (e >> 8);
-      const int col = strip * STRIP_W - STRIP_HALO + (e & 255);
-      if (row >= 0 && row < H && col >= 0 && col < W)
-        blur_s[e] = (unsigned char)gauss_chain_px<IN>(frame_base, p.in_pitch, W, H, row, col, ch);
-    }
-  }
-  wave_lds_sync();
+    reinterpret_cast<u32 *>(blur_s)[slot * 64 + lane] = bl;
+  };
 
-  // ------------------------------------------------------------------ phase 2: blur -> bit planes
+  // ------------------------------------------------------------------ phase 2 state: blur -> bit planes
   // Sobel is separable: per blur row d = b[+1]-b[-1], s = b[-1]+2b[0]+b[+1] (packed i16 pairs), then
   // sumX(i) = d[i-1]+2d[i]+d[i+1], sumY(i) = s[i-1]-s[i+1] (cannyEdgeD.cu:158-167).
   // S = sumX^2+sumY^2 by one v_dot2 per pixel; comparisons of the reference's float gradient are
@@ -358,39 +344,101 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
     for (int b = 0; b < 4; ++b) Vr[a][b] = 0;
 
   // this strip's 31 bytes of each bit-plane row: lane pair (2b+1, 2b+2) -> byte b
-  const size_t plane_off = (size_t)frame * H * p.RD * 4 + (size_t)strip * 31 + (size_t)((lane - 1) >> 1);
-  uint8_t *srow = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
-  uint8_t *crow = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
+  const size_t plane_off = (size_t)frame * H * p.RD * 4;   // wave-uniform
+  uint8_t *splane = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
+  uint8_t *cplane = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
   const bool store_lane = (lane & 1) && lane < 63;
-  const u32 a_lo0 = p.a_lo[0], a_hi0 = p.a_hi[0];
+  const u32 st_off = (u32)(strip * 31 + (lane >> 1));      // odd lanes only: (lane - 1) / 2
+  const u32 a_lo0 = p.a_lo[0], a_hi0 = p.a_hi[0], wrap_limit = p.wrap_limit;
 
-  constexpr int NSTEPS = CHUNK + 4;
-#pragma nounroll
-  for (int t0 = 0; t0 < NSTEPS; t0 += 6) {
+  // ------------------------------------------------------------------ the run
+#ifndef HC_FRONT_G
+#define HC_FRONT_G 2
+#endif
+  constexpr int G = HC_FRONT_G;  // rows per prefetch group (FSUB is a multiple of it)
+  u32 xn[G];
+  {  // warm-up: input rows r0-4 .. r0-1 only feed the accumulators (first blur row of the run is r0-2)
+    u32 xw[4];
 #pragma unroll
-    for (int u = 0; u < 6; ++u) {
-      const int t = t0 + u;
-      if (t >= NSTEPS) break;
-      const int k = r0 - 2 + t;  // blur row arriving
-      constexpr int dummy = 0;
-      (void)dummy;
-      const int rn = u % 2, rp = (u + 1) % 2;            // d/s ring: new row -> [rn] (holds row k-2), previous row k-1 in [rp]
-      const int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;  // S ring: new / centre / up
-      const u32 b = reinterpret_cast<const u32 *>(blur_s)[t * 64 + lane];
-      const u32 A = unpack_lo(b), B = unpack_hi(b);
-      const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
-      const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
-      u32 dk[2], sk[2];
-      dk[0] = R(I(p1) - I(m1));      // signed halves: packed op
-      sk[0] = pk_mad2(A, m1 + p1);   // non-negative halves < 2^16: plain add
-      dk[1] = R(I(p3) - I(p1));
-      sk[1] = pk_mad2(B, p1 + p3);
-      // Sobel row i = k-1 from blur rows k-2 (ring rn), k-1 (ring rp), k (new)
-      const int i = k - 1;
-      if (i >= 0 && i < H) {  // wave-uniform
+    for (int j = 0; j < 4; ++j) xw[j] = load_row(r0 - 4 + j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { u32 Sp[2]; accumulate(xw[j], Sp); }
+  }
+
+#pragma nounroll
+  for (int sub = 0; sub < p.subchunks; ++sub) {
+    const int b0 = r0 - 2 + sub * FSUB;  // blur row of slab slot 0 (input row b0 + 2)
+    if (b0 > rend + 1) break;            // NMS row c needs blur rows up to c + 2 <= rend + 1
+    qn = 0;
+#pragma unroll
+    for (int j = 0; j < G; ++j) xn[j] = load_row(b0 + 2 + j);
+#pragma nounroll
+    for (int g = 0; g < FSUB / G; ++g) {
+      u32 xc[G];
+#pragma unroll
+      for (int j = 0; j < G; ++j) xc[j] = xn[j];
+      if (g + 1 < FSUB / G)  // next group in flight while this one is processed (nothing is held across phase 2)
+#pragma unroll
+        for (int j = 0; j < G; ++j) xn[j] = load_row(b0 + 2 + (g + 1) * G + j);
+#pragma unroll
+      for (int j = 0; j < G; ++j) phase1_row(b0 + g * G + j, g * G + j, xc[j]);
+    }
+    // fix-up: the queued pixels get the literal chain.  If the queue overflowed (large flat regions:
+    // every pixel of a constant area has S = 159*v), every pixel of the slab is recomputed instead.
+    wave_lds_sync();
+    if (qn <= QCAP) {
+#pragma nounroll
+      for (int base = 0; base < qn; base += 64) {
+        const int e = base + lane;
+        const u32 ent = e < qn ? queue[e] : 0u;
+        u32 fl = ent & 0x80808080u;
+        const u32 el = ent & 63u, es = (ent >> 8) & 31u;
+        while (fl) {
+          const u32 k = (u32)__builtin_ctz(fl) >> 3;
+          fl &= fl - 1;
+          const int row = b0 + (int)es;
+          const int col = strip * STRIP_W - STRIP_HALO + (int)(el * 4u + k);
+          blur_s[es * 256u + el * 4u + k] = (unsigned char)gauss_chain_px<IN>(frame_base, p.in_pitch, W, H, row, col, ch);
+        }
+      }
+    } else {
+#pragma nounroll
+      for (int e = lane; e < FSUB * 256; e += 64) {  // e = slot*256 + lane'*4 + k
+        const int row = b0 + (e >> 8);
+        const int col = strip * STRIP_W - STRIP_HALO + (e & 255);
+        if (row >= 0 && row < H && col >= 0 && col < W)
+          blur_s[e] = (unsigned char)gauss_chain_px<IN>(frame_base, p.in_pitch, W, H, row, col, ch);
+      }
+    }
+    wave_lds_sync();
+
+    // the S-row halos of the two carried rows are re-fetched here so that they are dead during phase 1
+    Sr[1][0] = from_lane_below(Sr[1][4]); Sr[1][5] = from_lane_above(Sr[1][1]);
+    Sr[2][0] = from_lane_below(Sr[2][4]); Sr[2][5] = from_lane_above(Sr[2][1]);
+#pragma nounroll
+    for (int t0 = 0; t0 < FSUB; t0 += 6) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const int t = t0 + u;
+        const int k = b0 + t;  // blur row arriving
+        const int rn = u % 2, rp = (u + 1) % 2;            // d/s ring: new row -> [rn] (holds row k-2), previous row k-1 in [rp]
+        const int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;  // S ring: new / centre / up
+        const u32 b = reinterpret_cast<const u32 *>(blur_s)[t * 64 + lane];
+        const u32 A = unpack_lo(b), B = unpack_hi(b);
+        const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
+        const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
+        u32 dk[2], sk[2];
+        dk[0] = R(I(p1) - I(m1));      // signed halves: packed op
+        sk[0] = pk_mad2(A, m1 + p1);   // non-negative halves < 2^16: plain add
+        dk[1] = R(I(p3) - I(p1));
+        sk[1] = pk_mad2(B, p1 + p3);
+        // Sobel row i = k-1 from blur rows k-2 (ring rn), k-1 (ring rp), k (new); rows outside the image
+        // give 0 (zero padding of every stage): the column masks are cleared for them
+        const int i = k - 1;
+        const u32 rowm = (i >= 0 && i < H) ? 0xFFFFFFFFu : 0u;  // wave-uniform
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-          const u32 pm = h == 0 ? pm0 : pm1;  // sums outside the image are 0 (zero padding of every stage)
+          const u32 pm = (h == 0 ? pm0 : pm1) & rowm;
           const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;  // two's complement: the u16 mad is exact for i16
           const u32 Y = R(I(sr[rn][h]) - I(sk[h])) & pm;
           Vr[rn][2 * h + 0] = __builtin_amdgcn_perm(Y, X, 0x05040100u);  // (sumX, sumY) of pixel 2h
@@ -398,85 +446,92 @@ __global__ __launch_bounds__(256) void k_front(const FrontParams p)
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) Sr[sN][1 + q] = (u32)sdot2_0(Vr[rn][q], Vr[rn][q]);
-      } else {
+        Sr[sN][0] = from_lane_below(Sr[sN][4]);
+        Sr[sN][5] = from_lane_above(Sr[sN][1]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { Sr[sN][1 + q] = 0; Vr[rn][q] = 0; }
-      }
-      Sr[sN][0] = from_lane_below(Sr[sN][4]);
-      Sr[sN][5] = from_lane_above(Sr[sN][1]);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
+        for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
 
-      // NMS + thresholds for row c = k-2: centre ring sC (its V is in Vr[rp]), up sU, down sN
-      const int c = k - 2;
-      if (c >= r0 && c < H) {  // wave-uniform (c < r0 + CHUNK by the step count)
-        u32 nib = 0;
-        const u32 mx = max(max(Sr[sC][1], Sr[sC][2]), max(Sr[sC][3], Sr[sC][4]));
-        if (__ballot(mx >= a_lo0) != 0) {  // rows without a single candidate skip direction + NMS
-          const bool wrap = __ballot(mx >= p.wrap_limit) != 0;  // some gradient >= 256: u8 wrap bands needed
+        // NMS + thresholds for row c = k-2: centre ring sC (its V is in Vr[rp]), up sU, down sN
+        const int c = k - 2;
+        if (c >= r0 && c < rend) {  // wave-uniform
+          u32 nib = 0;
+          const u32 mx = max(max(Sr[sC][1], Sr[sC][2]), max(Sr[sC][3], Sr[sC][4]));
+          if (__ballot(mx >= a_lo0) != 0) {  // rows without a single candidate skip direction + NMS
+            // candidate / strong masks of the 4 pixel slots (wave-wide, in SGPR pairs)
+            u64 cl[4], st[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const u32 g = Sr[sC][1 + q];
-            u64 cl, st;
-            if (!wrap) {
-              cl = __ballot(g >= a_lo0);
-              st = __ballot(g >= a_hi0);
-            } else {
-              const u64 w0 = __ballot(g >= 262144u), w1 = __ballot(g >= 1048576u);
-              cl = (__ballot(g >= a_lo0) & ~w0) | (__ballot(g >= p.a_lo[1]) & ~w1) | __ballot(g >= p.a_lo[2]);
-              st = (__ballot(g >= a_hi0) & ~w0) | (__ballot(g >= p.a_hi[1]) & ~w1) | __ballot(g >= p.a_hi[2]);
+            for (int q = 0; q < 4; ++q) {
+              cl[q] = __ballot(Sr[sC][1 + q] >= a_lo0);
+              st[q] = __ballot(Sr[sC][1 + q] >= a_hi0);
             }
-            if (cl == 0) continue;  // no lane has a candidate in this pixel slot: skip direction + NMS
-            const u32 V = Vr[rp][q];
-            const i16x2 pm = { 1, -1 };
-            const int D = sdot2_0(V, R(I(V) * pm));
-            const int Q = sdot2_0(V, V >> 16);
-            const u64 p1m = __ballot(D - 2 * Q > 0), p2m = __ballot(D + 2 * Q > 0);
-            // neighbours (cannyEdgeD.cu:245-264): bin0 down/up, bin1 down-left/up-right, bin2 right/left, bin3 up-left/down-right
-            const u64 k0 = __ballot(max(Sr[sN][1 + q], Sr[sU][1 + q]) <= g);
-            const u64 k1 = __ballot(max(Sr[sN][q], Sr[sU][2 + q]) <= g);
-            const u64 k2 = __ballot(max(Sr[sC][2 + q], Sr[sC][q]) <= g);
-            const u64 k3 = __ballot(max(Sr[sU][q], Sr[sN][2 + q]) <= g);
-            const u64 keep = (~p1m & ~p2m & k0) | (~p1m & p2m & k1) | (p1m & p2m & k2) | (p1m & ~p2m & k3);
-            // per-lane nibbles (bit q = pixel slot q): strong in bits 0..3, candidate in bits 8..11
-            nib |= __builtin_amdgcn_inverse_ballot_w64(st & keep) ? (1u << q) : 0u;
-            nib |= __builtin_amdgcn_inverse_ballot_w64(cl & keep) ? (0x100u << q) : 0u;
+            if (__ballot(mx >= wrap_limit) != 0) {  // some gradient >= 256: the u8 wrap bands of cannyEdgeD.cu:267 apply (rare)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const u32 g = Sr[sC][1 + q];
+                const u64 w0 = __ballot(g >= 262144u), w1 = __ballot(g >= 1048576u);
+                cl[q] = (cl[q] & ~w0) | (__ballot(g >= p.a_lo[1]) & ~w1) | __ballot(g >= p.a_lo[2]);
+                st[q] = (st[q] & ~w0) | (__ballot(g >= p.a_hi[1]) & ~w1) | __ballot(g >= p.a_hi[2]);
+              }
+            }
+            u32 nibS = 0, nibC = 0;
+#pragma unroll
+            for (int q = 3; q >= 0; --q) {
+              u64 mS = 0, mC = 0;
+              if (cl[q] != 0) {  // some lane has a candidate in this pixel slot
+                const u32 g = Sr[sC][1 + q];
+                const u32 V = Vr[rp][q];
+                const i16x2 pmv = { 1, -1 };
+                const int D = sdot2_0(V, R(I(V) * pmv));                          // sumX^2 - sumY^2
+                const int Q2 = sdot2_0(V, __builtin_amdgcn_alignbyte(V, V, 2));   // 2 * sumX * sumY
+                const u64 p1m = __ballot(D > Q2), p2m = __ballot(D + Q2 > 0);
+                // neighbours (cannyEdgeD.cu:245-264): bin0 down/up, bin1 down-left/up-right, bin2 right/left, bin3 up-left/down-right.
+                // The four "both neighbours <= g" masks are combined with the direction masks by scalar logic
+                // (SALU issues beside the VALU; the kernel is VALU-issue-bound).
+                const u64 k0 = __ballot(max(Sr[sN][1 + q], Sr[sU][1 + q]) <= g);
+                const u64 k1 = __ballot(max(Sr[sN][q], Sr[sU][2 + q]) <= g);
+                const u64 k2 = __ballot(max(Sr[sC][2 + q], Sr[sC][q]) <= g);
+                const u64 k3 = __ballot(max(Sr[sU][q], Sr[sN][2 + q]) <= g);
+                const u64 keep = (~p1m & ~p2m & k0) | (~p1m & p2m & k1) | (p1m & p2m & k2) | (p1m & ~p2m & k3);
+                mS = st[q] & keep;
+                mC = cl[q] & keep;
+              }
+              // per-lane nibbles (bit q = pixel slot q): one carry-in add per mask
+              nibS = shift_in(nibS, mS);
+              nibC = shift_in(nibC, mC);
+            }
+            nib = (nibS | (nibC << 8)) & oknib;  // strong in bits 0..3, candidate in bits 8..11
           }
-          nib &= oknib;
-        }
-        const u32 w = nib | (from_lane_above(nib) << 4);  // bits 0..7 strong byte, 8..15 candidate byte
-        if (store_lane) {
-          srow[(size_t)c * p.RD * 4] = (uint8_t)w;
-          crow[(size_t)c * p.RD * 4] = (uint8_t)(w >> 8);
+          const u32 w = nib | (from_lane_above(nib) << 4);  // bits 0..7 strong byte, 8..15 candidate byte
+          if (store_lane) {
+            const u32 roff = (u32)c * plane_pitch;  // wave-uniform (a plane is < 4 GiB): scalar row base + 32-bit lane offset
+            u32 so = st_off;
+            asm volatile("" : "+v"(so));                // keeps the lane offset out of a hoisted 64-bit VGPR pointer
+            (splane + roff)[so] = (uint8_t)w;
+            (cplane + roff)[so] = (uint8_t)(w >> 8);
+          }
         }
       }
     }
+    wave_lds_sync();  // the next sub-chunk's phase 1 overwrites the slab
   }
 }
 
 template <int IN>
-static hipError_t launch_front_t(const FrontParams &p, int chunk_rows, hipStream_t s)
+static hipError_t launch_front_t(const FrontParams &p, hipStream_t s)
 {
   const int nblocks = (p.total_items + 3) / 4;
-  const size_t lds = front_lds_bytes(chunk_rows);
-  static bool attr_done = false;
-  if (!attr_done) {  // chunk 64 needs more than the default 64 KiB of dynamic LDS
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_front<64, IN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)front_lds_bytes(64));
-    attr_done = true;
-  }
-  switch (chunk_rows) {
-    case 8: hipLaunchKernelGGL((k_front<8, IN>), dim3(nblocks), dim3(256), lds, s, p); break;
-    case 16: hipLaunchKernelGGL((k_front<16, IN>), dim3(nblocks), dim3(256), lds, s, p); break;
-    case 32: hipLaunchKernelGGL((k_front<32, IN>), dim3(nblocks), dim3(256), lds, s, p); break;
-    case 64: hipLaunchKernelGGL((k_front<64, IN>), dim3(nblocks), dim3(256), lds, s, p); break;
-    default: return hipErrorInvalidValue;
-  }
+  size_t lds = front_lds_bytes();
+  static const int lds_pad = getenv("HC_FRONT_LDS") ? atoi(getenv("HC_FRONT_LDS")) : 0;  // experiments: occupancy cap via LDS
+  if (lds_pad > (int)lds && lds_pad <= 65536) lds = (size_t)lds_pad;
+  hipLaunchKernelGGL((k_front<IN>), dim3(nblocks), dim3(256), lds, s, p);
   return hipGetLastError();
 }
 
-hipError_t launch_front(const FrontParams &p, int chunk_rows, hipStream_t s)
+hipError_t launch_front(const FrontParams &p, hipStream_t s)
 {
-  return p.bgr == 2 ? launch_front_t<2>(p, chunk_rows, s) : p.bgr == 1 ? launch_front_t<1>(p, chunk_rows, s) : launch_front_t<0>(p, chunk_rows, s);
+  if (p.subchunks < 1 || p.run_rows != front_run_rows(p.subchunks) || p.nchunks * p.run_rows < p.H) return hipErrorInvalidValue;
+  if ((unsigned long long)p.H * p.in_pitch >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit row offsets inside a frame
+  return p.bgr == 2 ? launch_front_t<2>(p, s) : p.bgr == 1 ? launch_front_t<1>(p, s) : launch_front_t<0>(p, s);
 }
 
 // =================================================================================================
@@ -826,6 +881,9 @@ template <int NW, int TR, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 {
   if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
+  // latency-bound kernel (a few waves walking dependent row steps): when it shares a SIMD with the next
+  // run's k_front waves (pipelined mode) it should win the instruction arbitration
+  __builtin_amdgcn_s_setprio(3);
   constexpr int ROWW = 64 * NW;  // dwords per row
   constexpr int BR = WAVES * TR;
   __shared__ u32 edge[(2 * WAVES + 2) * ROWW];  // per wave: first and last row of S; then the two halo rows

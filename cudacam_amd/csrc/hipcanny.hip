@@ -288,8 +288,15 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   if (stage == HC_STAGE_HYSTER) {
     FrontParams fp{};
     fp.in = mono; fp.bgr = c->per_channel ? 2 : fuse_bgr ? 1 : 0; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = s.d_sbits; fp.cbits = s.d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
-    const int chunk = c->chunk ? c->chunk : 16;
-    fp.nstrips = c->nstrips; fp.nchunks = (H + chunk - 1) / chunk; fp.nframes = n_out;
+    // Mode R: a wave marches through `subchunks` sub-chunks of 24 blur rows (run of 24*m - 4 output rows).
+    // Longer runs amortise the 8-row warm-up; shorter runs give more work items (small batches).
+    int m = c->chunk ? (c->chunk + 4 + 23) / 24 : 0;
+    if (m == 0) {
+      m = 3;
+      while (m > 1 && (long)n_out * c->nstrips * ((H + front_run_rows(m) - 1) / front_run_rows(m)) < 24576) --m;
+    }
+    fp.subchunks = m; fp.run_rows = front_run_rows(m);
+    fp.nstrips = c->nstrips; fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows; fp.nframes = n_out;
     fp.total_items = n_out * fp.nstrips * fp.nchunks;
     if (c->mode == HC_MODE_O) {
       // cv::Canny: plain thresholds on the L1 magnitude; long chunks (no LDS slab, 4-row warm-up)
@@ -305,7 +312,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);
       band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
       fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
-      HIPCK(launch_front(fp, chunk, sf));
+      HIPCK(launch_front(fp, sf));
     }
     if (prof) HIPCK(hipEventRecord(ev[2], sf));
     if (piped) {
@@ -381,7 +388,14 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   };
   bool good = ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
   good = good && ok(hipStreamCreateWithFlags(&c->s_front, hipStreamNonBlocking), "hipStreamCreate");
-  good = good && ok(hipStreamCreateWithFlags(&c->s_hyst, hipStreamNonBlocking), "hipStreamCreate");
+  {
+    // pipelined mode: the hysteresis launches are few, small and dependent (latency-bound); at the highest
+    // priority their workgroups are placed ahead of the next run's 30k-wave front kernel instead of behind it
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (getenv("HC_NO_STREAM_PRIORITY")) greatest = least;
+    good = good && ok(hipStreamCreateWithPriority(&c->s_hyst, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
+  }
   good = good && ok(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming), "hipEventCreate");
   c->stream = c->own_stream;
   // (a BGR row is read in 12-byte groups of 4 pixels: keep room for the ragged last group)
@@ -448,7 +462,7 @@ int hc_set_stream(hc_ctx *c, void *s)
 int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
 {
   if (!c) return fail(HC_E_ARG, "null context");
-  if (chunk_rows != 0 && chunk_rows != 8 && chunk_rows != 16 && chunk_rows != 20 && chunk_rows != 24 && chunk_rows != 32 && chunk_rows != 64) return fail(HC_E_ARG, "chunk_rows must be 0, 8, 16, 20, 24, 32 or 64");
+  if (chunk_rows < 0 || chunk_rows > 16384) return fail(HC_E_ARG, "chunk_rows must be 0 (auto) or 1..16384");
   if (hyst_launches < 1 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range");
   if (int rc = finish_all(c)) return rc;
   c->chunk = chunk_rows; c->hyst_launches = hyst_launches;

@@ -56,7 +56,7 @@ def test_all_stages_mono(oracle, name, img):
             _diff(got, want[key], f"{name} stage {stage.name}")
 
 
-@pytest.mark.parametrize("chunk", [16, 32, 64])
+@pytest.mark.parametrize("chunk", [20, 44, 116, 1080])
 def test_chunk_invariance(oracle, chunk):
     img = synth.natural(700, 333, 11)
     want = oracle.canny_r(img, 10, 40)
