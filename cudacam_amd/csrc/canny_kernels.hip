@@ -537,7 +537,7 @@ hipError_t launch_front(const FrontParams &p, hipStream_t s)
 // =================================================================================================
 // k_front_o: "Mode O" -- cv::Canny(src 8UC1, low, high, apertureSize 3, L2gradient false) semantics
 // =================================================================================================
-// OpenCV 4.x modules/imgproc/src/canny.cpp as restated in oracle/canny_oracle.c (orc_canny_o): no blur,
+// OpenCV 4.x modules/imgproc/src/canny.cpp (the parity tests check it against a CPU restatement): no blur,
 // Sobel 3x3 on the source with BORDER_REPLICATE, L1 magnitude m = |dx|+|dy| (0 outside the image),
 // pixels with m <= low are dropped, direction by the integer tangent test (TG22 = 13573, shift 15),
 // asymmetric non-maximum suppression (m > first neighbour, m >= second on the axes; strict on both
