@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--hyst-launches", type=int, default=6)
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
+    ap.add_argument("--fused", action="store_true", help="HC_OPT_FRONT_SPLIT = 0: the single fused front kernel instead of k_blur + k_nms")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -85,6 +86,8 @@ def main():
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
     ctx.set_option(api.OPT_PIPELINE, 0 if a.no_pipeline else 1)
+    if a.mode == "R":
+        ctx.set_option(api.OPT_FRONT_SPLIT, 0 if a.fused else 1)
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
@@ -141,7 +144,7 @@ def main():
                        "pipeline": not a.no_pipeline},
             "e2e_alg_GBps": round(2.0 * W * H * frames_total / elapsed / 1e9, 1),
             "roofline": {
-                "bound": "hbm", "kernel": "k_front" if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": ("k_front" if a.fused else "k_blur+k_nms") if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(achieved / HBM_MEASURED_COPY_GBPS, 4),
                 "traffic": None, "kernel_ms": round(front_ms, 4), "hyst_expand_ms": round(hyst_ms, 4), "launches_timed": nruns,
             },

@@ -42,6 +42,7 @@ MODE_R, MODE_O = 0, 1
 OPT_NMS_SATURATE = 1
 OPT_PIPELINE = 2
 OPT_PER_CHANNEL = 3
+OPT_FRONT_SPLIT = 4
 
 # every symbol include/hipcanny.h declares
 ABI_SYMBOLS = [

@@ -37,6 +37,10 @@ struct FrontParams {
   int total_items;         // nframes * nstrips * nchunks
   // thresholds on S = sumX^2 + sumY^2 for "u8-wrapped gradient > T" (band test)
   u32 a_lo[3], a_hi[3];
+  // split mode (k_blur + k_nms): the u8 blur plane between the two kernels and k_nms's own work split
+  uint8_t *blur;             // [frame][strip][H][256]: one aligned 256-byte row per wave-row (bytes 4..251 = the strip's columns)
+  size_t blur_frame_stride;  // >= nstrips * H * 256
+  int nchunks_b, run_rows_b, total_items_b;
   u32 wrap_limit;  // S >= wrap_limit: gradient >= 256, the wrap bands apply (0xFFFFFFFF: saturating variant)
 };
 
@@ -80,6 +84,8 @@ hipError_t launch_selftest(u32 *d_result, hipStream_t s);
 hipError_t upload_gauss_coeffs(const float gk[25]);
 hipError_t launch_front(const FrontParams &p, hipStream_t s);
 hipError_t launch_front_o(const FrontParams &p, hipStream_t s);
+hipError_t launch_blur(const FrontParams &p, hipStream_t s);
+hipError_t launch_nms(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 hipError_t launch_expand(const ExpandParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);

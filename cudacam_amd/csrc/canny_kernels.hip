@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace hc {
 
@@ -60,6 +61,27 @@ static __device__ __forceinline__ u32 R(i16x2 v) { return __builtin_bit_cast(u32
 // the accumulate form (v_dot2c) that needs an extra v_mov 0
 static __device__ __forceinline__ u32 pk_mad2(u32 a, u32 c) { u32 d; asm("v_pk_mad_u16 %0, %1, 2, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c)); return d; }
 static __device__ __forceinline__ u32 pk_mul5(u32 a) { u32 d; asm("v_pk_mul_lo_u16 %0, %1, 5 op_sel_hi:[1,0]" : "=v"(d) : "v"(a)); return d; }
+// 16 x 16 -> 32 bit signed multiply-add on a chosen half (HA / HB: 0 = low, 1 = high) of each packed operand
+template <int HA, int HB>
+static __device__ __forceinline__ int mad16(u32 a, u32 b, int c)
+{
+  int d;
+  if (HA == 0 && HB == 0) asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  else if (HA == 1 && HB == 1) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  else if (HA == 1) asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  else asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+template <int HA, int HB>
+static __device__ __forceinline__ int mul16(u32 a, u32 b)
+{
+  int d;
+  if (HA == 0 && HB == 0) asm("v_mad_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+  else if (HA == 1 && HB == 1) asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,1,0,0]" : "=v"(d) : "v"(a), "v"(b));
+  else if (HA == 1) asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[1,0,0,0]" : "=v"(d) : "v"(a), "v"(b));
+  else asm("v_mad_i32_i16 %0, %1, %2, 0 op_sel:[0,1,0,0]" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
 static __device__ __forceinline__ int sdot2_0(u32 a, u32 b) { int d; asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b)); return d; }
 // v*2 + (bit of `mask` for this lane): shifts one ballot mask into per-lane words (carry-in form of v_addc)
 static __device__ __forceinline__ u32 shift_in(u32 v, u64 mask)
@@ -116,6 +138,14 @@ __global__ void k_selftest(u32 *res)
   bad |= (m != 0xAAAAAAAAAAAAAAAAull) ? 1024u : 0u;
   bad |= (mbcnt64(m) != lane / 2) ? 2048u : 0u;
   bad |= (shift_in(lane, m) != 2 * lane + (lane & 1)) ? 4096u : 0u;
+  {
+    const int xl = (int)lane - 32, xh = 1000 - 3 * (int)lane;            // packed i16 pair (xl, xh)
+    const u32 pk = ((u32)xl & 0xFFFFu) | ((u32)xh << 16);
+    bad |= (mul16<0, 0>(pk, pk) != xl * xl) ? 8192u : 0u;
+    bad |= (mul16<1, 1>(pk, pk) != xh * xh) ? 8192u : 0u;
+    bad |= (mad16<0, 1>(pk, pk, 7) != xl * xh + 7) ? 8192u : 0u;
+    bad |= (mad16<1, 0>(pk, pk, -5) != xh * xl - 5) ? 8192u : 0u;
+  }
   if (bad) atomicOr(res, bad);
 }
 
@@ -329,19 +359,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HC_FRONT_WA
   // All rings below are indexed by compile-time constants (the row loop is unrolled by 6 = lcm(2,3)).
   u32 dr[2][2], sr[2][2];  // d and s of the two previous blur rows, [ring][pair]
   u32 Sr[3][6];            // S rows: [ring][0]=left neighbour, [1..4]=own 4 px, [5]=right neighbour
-  u32 Vr[2][4];            // packed (sumX,sumY) of the two newest Sobel rows
+  u32 Xr[2][2], Yr[2][2];  // packed sumX / sumY pairs of the two newest Sobel rows, [ring][pair]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) dr[a][b] = sr[a][b] = 0;
+    for (int b = 0; b < 2; ++b) dr[a][b] = sr[a][b] = Xr[a][b] = Yr[a][b] = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int b = 0; b < 6; ++b) Sr[a][b] = 0;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) Vr[a][b] = 0;
 
   // this strip's 31 bytes of each bit-plane row: lane pair (2b+1, 2b+2) -> byte b
   const size_t plane_off = (size_t)frame * H * p.RD * 4;   // wave-uniform
@@ -441,30 +467,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HC_FRONT_WA
           const u32 pm = (h == 0 ? pm0 : pm1) & rowm;
           const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;  // two's complement: the u16 mad is exact for i16
           const u32 Y = R(I(sr[rn][h]) - I(sk[h])) & pm;
-          Vr[rn][2 * h + 0] = __builtin_amdgcn_perm(Y, X, 0x05040100u);  // (sumX, sumY) of pixel 2h
-          Vr[rn][2 * h + 1] = __builtin_amdgcn_perm(Y, X, 0x07060302u);  // pixel 2h+1
+          Xr[rn][h] = X;
+          Yr[rn][h] = Y;
+          // S = sumX^2 + sumY^2 (< 2^22): two 16x16 multiply-adds per pixel on the packed halves
+          Sr[sN][1 + 2 * h] = (u32)mad16<0, 0>(X, X, mul16<0, 0>(Y, Y));
+          Sr[sN][2 + 2 * h] = (u32)mad16<1, 1>(X, X, mul16<1, 1>(Y, Y));
         }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Sr[sN][1 + q] = (u32)sdot2_0(Vr[rn][q], Vr[rn][q]);
         Sr[sN][0] = from_lane_below(Sr[sN][4]);
         Sr[sN][5] = from_lane_above(Sr[sN][1]);
 #pragma unroll
         for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
 
-        // NMS + thresholds for row c = k-2: centre ring sC (its V is in Vr[rp]), up sU, down sN
+        // NMS + thresholds for row c = k-2: centre ring sC (its sumX/sumY are in ring rp), up sU, down sN
         const int c = k - 2;
         if (c >= r0 && c < rend) {  // wave-uniform
           u32 nib = 0;
-          const u32 mx = max(max(Sr[sC][1], Sr[sC][2]), max(Sr[sC][3], Sr[sC][4]));
-          if (__ballot(mx >= a_lo0) != 0) {  // rows without a single candidate skip direction + NMS
-            // candidate / strong masks of the 4 pixel slots (wave-wide, in SGPR pairs)
-            u64 cl[4], st[4];
+          // candidate masks of the 4 pixel slots (wave-wide, in SGPR pairs); rows without a single candidate skip the rest
+          u64 cl[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              cl[q] = __ballot(Sr[sC][1 + q] >= a_lo0);
-              st[q] = __ballot(Sr[sC][1 + q] >= a_hi0);
-            }
-            if (__ballot(mx >= wrap_limit) != 0) {  // some gradient >= 256: the u8 wrap bands of cannyEdgeD.cu:267 apply (rare)
+          for (int q = 0; q < 4; ++q) cl[q] = __ballot(Sr[sC][1 + q] >= a_lo0);
+          if ((cl[0] | cl[1] | cl[2] | cl[3]) != 0) {
+            u64 st[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) st[q] = __ballot(Sr[sC][1 + q] >= a_hi0);
+            // a gradient >= 256 (S >= 2^18 >= the strong threshold) makes the u8 wrap bands of cannyEdgeD.cu:267 apply (rare)
+            if ((st[0] | st[1] | st[2] | st[3]) != 0 && __ballot(max(max(Sr[sC][1], Sr[sC][2]), max(Sr[sC][3], Sr[sC][4])) >= wrap_limit) != 0) {
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 const u32 g = Sr[sC][1 + q];
@@ -474,16 +501,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HC_FRONT_WA
               }
             }
             u32 nibS = 0, nibC = 0;
-#pragma unroll
-            for (int q = 3; q >= 0; --q) {
+            // direction bins (cannyEdgeD.cu:239-264) without atan2: with x = sumX, y = sumY
+            //   E1 = x^2 - 2xy - y^2 = 2x(x - y) - S,  E2 = x^2 + 2xy - y^2 = 2x(x + y) - S;
+            //   E1 > 0 && E2 > 0: bin 2, neither: bin 0, only E1: bin 3, only E2: bin 1.
+            // 2x, x - y, x + y are formed once per packed pair, the two products are 16x16 multiplies.
+            auto slot = [&](auto hc, auto ec, u32 A2, u32 Um, u32 Vp) {
+              constexpr int h = decltype(hc)::value, e = decltype(ec)::value, q = 2 * h + e;
               u64 mS = 0, mC = 0;
               if (cl[q] != 0) {  // some lane has a candidate in this pixel slot
                 const u32 g = Sr[sC][1 + q];
-                const u32 V = Vr[rp][q];
-                const i16x2 pmv = { 1, -1 };
-                const int D = sdot2_0(V, R(I(V) * pmv));                          // sumX^2 - sumY^2
-                const int Q2 = sdot2_0(V, __builtin_amdgcn_alignbyte(V, V, 2));   // 2 * sumX * sumY
-                const u64 p1m = __ballot(D > Q2), p2m = __ballot(D + Q2 > 0);
+                const u64 p1m = __ballot(mul16<e, e>(A2, Um) > (int)g), p2m = __ballot(mul16<e, e>(A2, Vp) > (int)g);
                 // neighbours (cannyEdgeD.cu:245-264): bin0 down/up, bin1 down-left/up-right, bin2 right/left, bin3 up-left/down-right.
                 // The four "both neighbours <= g" masks are combined with the direction masks by scalar logic
                 // (SALU issues beside the VALU; the kernel is VALU-issue-bound).
@@ -498,12 +525,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HC_FRONT_WA
               // per-lane nibbles (bit q = pixel slot q): one carry-in add per mask
               nibS = shift_in(nibS, mS);
               nibC = shift_in(nibC, mC);
-            }
+            };
+            auto pair = [&](auto hc) {
+              constexpr int h = decltype(hc)::value;
+              const u32 X = Xr[rp][h], Y = Yr[rp][h];
+              const u32 A2 = R(U(X) + U(X));   // packed 2x (|x| <= 1020)
+              const u32 Um = R(I(X) - I(Y));
+              const u32 Vp = R(U(X) + U(Y));   // wrap-around add = signed add
+              slot(hc, std::integral_constant<int, 1>{}, A2, Um, Vp);
+              slot(hc, std::integral_constant<int, 0>{}, A2, Um, Vp);
+            };
+            pair(std::integral_constant<int, 1>{});  // slots 3, 2
+            pair(std::integral_constant<int, 0>{});  // slots 1, 0
             nib = (nibS | (nibC << 8)) & oknib;  // strong in bits 0..3, candidate in bits 8..11
           }
           const u32 w = nib | (from_lane_above(nib) << 4);  // bits 0..7 strong byte, 8..15 candidate byte
           if (store_lane) {
-            const u32 roff = (u32)c * plane_pitch;  // wave-uniform (a plane is < 4 GiB): scalar row base + 32-bit lane offset
+            // wave-uniform row base (a plane is < 4 GiB) + 32-bit lane offset.  The multiply is pinned to the
+            // SALU: as plain C it became a VGPR induction variable and 9 VALU ops per row to rebuild the pointers
+            u32 roff;
+            asm("s_mul_i32 %0, %1, %2" : "=s"(roff) : "s"(c), "s"(plane_pitch));
             u32 so = st_off;
             asm volatile("" : "+v"(so));                // keeps the lane offset out of a hoisted 64-bit VGPR pointer
             (splane + roff)[so] = (uint8_t)w;
@@ -532,6 +573,415 @@ hipError_t launch_front(const FrontParams &p, hipStream_t s)
   if (p.subchunks < 1 || p.run_rows != front_run_rows(p.subchunks) || p.nchunks * p.run_rows < p.H) return hipErrorInvalidValue;
   if ((unsigned long long)p.H * p.in_pitch >= (1ull << 32)) return hipErrorInvalidValue;  // 32-bit row offsets inside a frame
   return p.bgr == 2 ? launch_front_t<2>(p, s) : p.bgr == 1 ? launch_front_t<1>(p, s) : launch_front_t<0>(p, s);
+}
+
+// =================================================================================================
+// k_blur + k_nms: the front path as two kernels ("split" mode, the default)
+// =================================================================================================
+// The fused k_front above carries the vertical blur accumulators through its Sobel/NMS phase and the
+// Sobel/NMS rings through its blur phase: ~90 VGPRs, 4-5 waves per SIMD, and a VALU pipe that is only
+// ~75 % busy.  Split in two, each half needs < 64 VGPRs (8 waves per SIMD), no LDS slab, and runs can be
+// long (a 4-row warm-up per 135 rows instead of 8 per 68).  The price is one u8 blur plane through HBM
+// (1 B/px written, 1 B/px read back): 4 MB per 1080p frame against kernels that are VALU-bound.
+//   k_blur   input rows -> exact Gaussian blur (u8), written to the blur plane
+//   k_nms    blur plane -> Sobel -> S -> direction -> NMS -> thresholds -> the two bit planes
+// Blur plane layout: [frame][strip][H][256 B] -- every wave-row of k_blur is one aligned 256-byte store of
+// all 64 lanes (two full 128 B lines; a [H][W] plane would take 248-byte pieces at unaligned offsets, and
+// the L2 fetches every partially written line first: measured 2.6x read amplification).  Bytes 4..251 of a
+// segment row are the strip's own 248 columns; the two halo dwords are junk and never read: k_nms takes its
+// halo columns from the neighbouring strips' segments.
+constexpr int BSUB = 24;   // blur rows between two fix-up passes of k_blur
+constexpr int BRING = 32;  // input rows (masked, grey) kept in a wave-private LDS ring for the fix-up: >= BSUB + 4, power of 2
+constexpr int BLUR_WAVE_BYTES = BRING * 256 + QCAP * 4;
+
+// the literal reference chain (cannyEdgeD.cu:102-115) on the LDS ring: rows and columns outside the image
+// are stored as 0 there, and a 0 tap leaves the running sum unchanged (c * 0 = 0, f + 0 = f), exactly as
+// the reference's skipped taps do -- so no bounds checks and no scattered global loads.
+static __device__ __forceinline__ u32 gauss_chain_lds(const unsigned char *ring, int row, u32 colbyte)
+{
+  float f = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const unsigned char *q = ring + (u32)((row - 2 + r) & (BRING - 1)) * 256u + colbyte - 2u;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) f = __builtin_fmaf(GKC.v[r * 5 + c], (float)q[c], f);
+  }
+  return (u32)(int)f;
+}
+
+template <int IN>
+__global__ __launch_bounds__(256) void k_blur(const FrontParams p)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  unsigned char *ring = smem + wib * BLUR_WAVE_BYTES;
+  u32 *queue = reinterpret_cast<u32 *>(ring + BRING * 256);
+
+  const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
+  if (item >= p.total_items) return;
+  const int chunk = item % p.nchunks;
+  const int strip = (item / p.nchunks) % p.nstrips;
+  const int frame = item / (p.nchunks * p.nstrips);  // output frame (per-channel mode: 3 per input frame)
+  const int in_frame = IN == 2 ? frame / 3 : frame, ch = IN == 2 ? frame % 3 : 0;
+  const int W = p.W, H = p.H;
+  const int r0 = chunk * p.run_rows;  // blur rows [r0, rend)
+  const int rend = min(r0 + p.run_rows, H);
+  const int c0 = strip * STRIP_W - STRIP_HALO + lane * PX_PER_LANE;
+
+  u32 cmask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool in = (c0 + k >= 0) && (c0 + k < W);
+    cmask |= in ? (0xFFu << (8 * k)) : 0u;
+  }
+  const bool own_lane = lane >= 1 && lane <= 62;                // lanes 0 and 63 only feed their neighbours' taps
+  const u32 hmask = own_lane ? (cmask & 0x80808080u) : 0u;      // "undecidable" flag positions this lane is responsible for
+  const bool col_any = cmask != 0;
+  const uint8_t *frame_base = p.in + (size_t)in_frame * p.in_frame_stride;
+  const u32 in_pitch32 = (u32)p.in_pitch;                       // launch_blur checks H * pitch < 2^32
+  const u32 ld_off = (u32)((IN ? 3 : 1) * c0);
+  const u32 selA = ch == 0 ? 0x0c060300u : ch == 1 ? 0x0c070401u : 0x0c0c0502u;
+  const u32 selB = ch == 0 ? 0x05020100u : ch == 1 ? 0x06020100u : 0x07040100u;
+  uint8_t *bseg = p.blur + (size_t)frame * p.blur_frame_stride + (size_t)strip * H * 256;  // this strip's segment (wave-uniform)
+  const u32 bo = (u32)(4 * lane);
+
+  auto load_row = [&](int row) -> u32 {  // same input forms as k_front
+    u32 v = 0;
+    if (row >= 0 && row < H && col_any) {
+      const uint8_t *rowp = frame_base + (u32)row * in_pitch32;
+      u32 lo = ld_off;
+      asm volatile("" : "+v"(lo));
+      if (IN == 2) {
+        const u32 *q = reinterpret_cast<const u32 *>(rowp + lo);
+        const u32 t = __builtin_amdgcn_perm(q[1], q[0], selA);
+        v = __builtin_amdgcn_perm(q[2], t, selB);
+      } else if (IN == 1) {
+        const u32 *q = reinterpret_cast<const u32 *>(rowp + lo);
+        const u32 d0 = q[0], d1 = q[1], d2 = q[2];
+        const u32 wts = 0x00132607u;
+        const u32 m0 = __builtin_amdgcn_udot4(d0, wts, 0u, false) >> 6;
+        const u32 m1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), wts, 0u, false) >> 6;
+        const u32 m2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), wts, 0u, false) >> 6;
+        const u32 m3 = __builtin_amdgcn_udot4(d2 >> 8, wts, 0u, false) >> 6;
+        v = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+      } else v = *reinterpret_cast<const u32 *>(rowp + lo);
+    }
+    return v;
+  };
+
+  // vertical accumulators, as in k_front (see the derivation there)
+  u32 a1[2] = { 0, 0 }, a2[2] = { 0, 0 }, a3[2] = { 0, 0 }, a4[2] = { 0, 0 };
+  auto accumulate = [&](u32 xraw, u32 Sp[2]) {
+    const u32 x = xraw & cmask;
+    const u32 A = unpack_lo(x), B = unpack_hi(x);
+    const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
+    const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32 P = h == 0 ? Bl + B : A + Ar;
+      const u32 Q = h == 0 ? m1 + p1 : p1 + p3;
+      const u32 Cc = h == 0 ? A : B;
+      const u32 e = pk_mad2(Q, P);
+      const u32 h0 = pk_mad2(e, pk_mul5(Cc));
+      const u32 w = pk_mad2(Cc, Q);
+      const u32 h1 = pk_mad2(h0, w);
+      const u32 h2 = (h0 + h1) - (P + w);
+      Sp[h] = a4[h] + h0;
+      a4[h] = a3[h] + h1;
+      a3[h] = a2[h] + h2;
+      a2[h] = a1[h] + h1;
+      a1[h] = h0;
+    }
+  };
+
+  int qn = 0;
+  // input row rb + 2 completes blur row rb; `slot` = rb - b0 inside the current fix-up window
+  auto blur_row = [&](int rb, int slot, u32 xraw) {
+    u32 Sp[2];
+    reinterpret_cast<u32 *>(ring)[((rb + 2) & (BRING - 1)) * 64 + lane] = xraw & cmask;
+    accumulate(xraw, Sp);
+    if (rb < rend) {  // wave-uniform (rb >= r0 >= 0 by construction)
+      const u16x2 mlo = { 52759, 0 }, mhi = { 0, 52759 };
+      const u32 t0 = __builtin_amdgcn_udot2(U(Sp[0]), mlo, 0u, false) >> 15;
+      const u32 t1 = __builtin_amdgcn_udot2(U(Sp[0]), mhi, 0u, false) >> 15;
+      const u32 t2 = __builtin_amdgcn_udot2(U(Sp[1]), mlo, 0u, false) >> 15;
+      const u32 t3 = __builtin_amdgcn_udot2(U(Sp[1]), mhi, 0u, false) >> 15;
+      const u32 nf01 = __builtin_amdgcn_perm(t1, t0, 0x04000501u);
+      const u32 nf23 = __builtin_amdgcn_perm(t3, t2, 0x04000501u);
+      const u32 bl = __builtin_amdgcn_perm(nf23, nf01, 0x05040100u) & cmask;
+      const u32 fz = __builtin_amdgcn_perm(nf23, nf01, 0x07060302u);
+      const u32 hz = (fz - 0x01010101u) & ~fz & hmask;
+      const u64 any = __ballot(hz != 0);
+      if (any != 0) {
+        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(any >> 32), __builtin_amdgcn_mbcnt_lo((u32)any, (u32)qn));
+        if (hz != 0 && rank < (u32)QCAP) queue[rank] = hz | (u32)lane | ((u32)slot << 8);
+        qn += __popcll(any);
+      }
+      {
+        u32 o = bo;
+        asm volatile("" : "+v"(o));
+        *reinterpret_cast<u32 *>(bseg + (u32)rb * 256u + o) = bl;  // all 64 lanes: one aligned 256-byte row
+      }
+    }
+  };
+
+  // The kernel is bound by memory latency, not arithmetic (a row is ~60 VALU ops): the G rows of the next
+  // group are requested before the current group is processed.  (The compiler drains the memory counter
+  // once per loop trip, vmcnt(0), so loads issued inside the group would be waited for almost at once.)
+  constexpr int G = 8;
+  static_assert(BSUB % G == 0, "fix-up windows are whole groups");
+  {  // warm-up: input rows r0-2 .. r0+1 only feed the accumulators
+    u32 xw[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xw[j] = load_row(r0 - 2 + j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u32 Sp[2];
+      reinterpret_cast<u32 *>(ring)[((r0 - 2 + j) & (BRING - 1)) * 64 + lane] = xw[j] & cmask;
+      accumulate(xw[j], Sp);
+    }
+  }
+  u32 xn[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) xn[j] = load_row(r0 + 2 + j);
+  int wb0 = r0;  // first blur row of the current fix-up window
+#pragma nounroll
+  for (int rb0 = r0; rb0 < rend; rb0 += G) {
+    u32 xc[G];
+#pragma unroll
+    for (int j = 0; j < G; ++j) xc[j] = xn[j];
+    if (rb0 + G < rend)
+#pragma unroll
+      for (int j = 0; j < G; ++j) xn[j] = load_row(rb0 + 2 + G + j);
+#pragma unroll
+    for (int j = 0; j < G; ++j) blur_row(rb0 + j, rb0 - wb0 + j, xc[j]);
+    if (rb0 + G - wb0 < BSUB && rb0 + G < rend) continue;
+    // fix-up of the window [wb0, rb0 + G): the queued pixels get the literal chain, written over the plane
+    // bytes (same wave, program order).  Queue overflow (flat areas): every pixel of the window is recomputed.
+    wave_lds_sync();
+    if (qn <= QCAP) {
+#pragma nounroll
+      for (int base = 0; base < qn; base += 64) {
+        const int e = base + lane;
+        const u32 ent = e < qn ? queue[e] : 0u;
+        u32 fl = ent & 0x80808080u;
+        const u32 el = ent & 63u, es = (ent >> 8) & 31u;
+        while (fl) {
+          const u32 k = (u32)__builtin_ctz(fl) >> 3;
+          fl &= fl - 1;
+          const int row = wb0 + (int)es;
+          bseg[(u32)row * 256u + el * 4u + k] = (unsigned char)gauss_chain_lds(ring, row, el * 4u + k);
+        }
+      }
+    } else {
+      const int nrows = min(rb0 + G, rend) - wb0;
+#pragma nounroll
+      for (int e = lane; e < nrows * STRIP_W; e += 64) {
+        const int row = wb0 + e / STRIP_W;
+        const int col = strip * STRIP_W + e % STRIP_W;
+        if (col < W) bseg[(u32)row * 256u + 4u + (u32)(e % STRIP_W)] = (unsigned char)gauss_chain_lds(ring, row, 4u + (u32)(e % STRIP_W));
+      }
+    }
+    wave_lds_sync();
+    wb0 = rb0 + G;
+    qn = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nms(const FrontParams p)
+{
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
+  if (item >= p.total_items_b) return;
+  const int chunk = item % p.nchunks_b;
+  const int strip = (item / p.nchunks_b) % p.nstrips;
+  const int frame = item / (p.nchunks_b * p.nstrips);
+  const int W = p.W, H = p.H;
+  const int r0 = chunk * p.run_rows_b;  // output rows [r0, rend)
+  const int rend = min(r0 + p.run_rows_b, H);
+  const int c0 = strip * STRIP_W - STRIP_HALO + lane * PX_PER_LANE;
+
+  u32 cmask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool in = (c0 + k >= 0) && (c0 + k < W);
+    cmask |= in ? (0xFFu << (8 * k)) : 0u;
+  }
+  const u32 pm0 = __builtin_amdgcn_perm(0u, cmask, 0x01010000u), pm1 = __builtin_amdgcn_perm(0u, cmask, 0x03030202u);
+  const u32 oknib1 = (lane >= 1 && lane <= 62) ? ((cmask & 1u) | ((cmask >> 7) & 2u) | ((cmask >> 14) & 4u) | ((cmask >> 21) & 8u)) : 0u;
+  const u32 oknib = oknib1 | (oknib1 << 8);
+  // own columns from this strip's segment; the halo lanes read the dword the neighbouring strip owns
+  // (lane 0 <- strip-1 lane 62, lane 63 <- strip+1 lane 1); lanes without an image column read nothing (0)
+  const uint8_t *bframe = p.blur + (size_t)frame * p.blur_frame_stride;  // wave-uniform
+  const int seg = lane == 0 ? strip - 1 : lane == 63 ? strip + 1 : strip;
+  const u32 bo = (u32)seg * (u32)H * 256u + (lane == 0 ? 248u : lane == 63 ? 4u : (u32)(4 * lane));
+  const bool col_any = cmask != 0;  // false for lane 0 of strip 0 and for lanes right of the image (incl. a missing strip+1)
+  auto load_b = [&](int k) -> u32 {  // blur rows outside the image are 0 (zero padding, cannyEdgeD.cu:150-156)
+    u32 v = 0;
+    if (k >= 0 && k < H && col_any) {
+      u32 o = bo;
+      asm volatile("" : "+v"(o));
+      v = *reinterpret_cast<const u32 *>(bframe + (u32)k * 256u + o);
+    }
+    return v;
+  };
+
+  u32 dr[2][2], sr[2][2];  // d and s of the two previous blur rows, [ring][pair]
+  u32 Sr[3][6];            // S rows: [ring][0]=left neighbour, [1..4]=own 4 px, [5]=right neighbour
+  u32 Xr[2][2], Yr[2][2];  // packed sumX / sumY pairs of the two newest Sobel rows
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) dr[a][b] = sr[a][b] = Xr[a][b] = Yr[a][b] = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 6; ++b) Sr[a][b] = 0;
+
+  const size_t plane_off = (size_t)frame * H * p.RD * 4;
+  uint8_t *splane = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
+  uint8_t *cplane = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
+  const bool store_lane = (lane & 1) && lane < 63;
+  const u32 st_off = (u32)(strip * 31 + (lane >> 1));
+  const u32 a_lo0 = p.a_lo[0], a_hi0 = p.a_hi[0], wrap_limit = p.wrap_limit;
+  const u32 plane_pitch = (u32)p.RD * 4u;
+
+  // one step: blur row k arrives -> Sobel row k-1 -> NMS/threshold row k-2 (see k_front's phase 2)
+  auto step = [&](auto uc, int k, u32 b) {
+    constexpr int u = decltype(uc)::value;
+    constexpr int rn = u % 2, rp = (u + 1) % 2;
+    constexpr int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;
+    const u32 A = unpack_lo(b), B = unpack_hi(b);
+    const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
+    const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
+    u32 dk[2], sk[2];
+    dk[0] = R(I(p1) - I(m1));
+    sk[0] = pk_mad2(A, m1 + p1);
+    dk[1] = R(I(p3) - I(p1));
+    sk[1] = pk_mad2(B, p1 + p3);
+    const int i = k - 1;
+    const u32 rowm = (i >= 0 && i < H) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32 pm = (h == 0 ? pm0 : pm1) & rowm;
+      const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;
+      const u32 Y = R(I(sr[rn][h]) - I(sk[h])) & pm;
+      Xr[rn][h] = X;
+      Yr[rn][h] = Y;
+      Sr[sN][1 + 2 * h] = (u32)mad16<0, 0>(X, X, mul16<0, 0>(Y, Y));
+      Sr[sN][2 + 2 * h] = (u32)mad16<1, 1>(X, X, mul16<1, 1>(Y, Y));
+    }
+    Sr[sN][0] = from_lane_below(Sr[sN][4]);
+    Sr[sN][5] = from_lane_above(Sr[sN][1]);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
+
+    const int c = k - 2;
+    if (c >= r0 && c < rend) {
+      u32 nib = 0;
+      u64 cl[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cl[q] = __ballot(Sr[sC][1 + q] >= a_lo0);
+      if ((cl[0] | cl[1] | cl[2] | cl[3]) != 0) {
+        u64 st[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) st[q] = __ballot(Sr[sC][1 + q] >= a_hi0);
+        if ((st[0] | st[1] | st[2] | st[3]) != 0 && __ballot(max(max(Sr[sC][1], Sr[sC][2]), max(Sr[sC][3], Sr[sC][4])) >= wrap_limit) != 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const u32 g = Sr[sC][1 + q];
+            const u64 w0 = __ballot(g >= 262144u), w1 = __ballot(g >= 1048576u);
+            cl[q] = (cl[q] & ~w0) | (__ballot(g >= p.a_lo[1]) & ~w1) | __ballot(g >= p.a_lo[2]);
+            st[q] = (st[q] & ~w0) | (__ballot(g >= p.a_hi[1]) & ~w1) | __ballot(g >= p.a_hi[2]);
+          }
+        }
+        u32 nibS = 0, nibC = 0;
+        auto slot = [&](auto hc, auto ec, u32 A2, u32 Um, u32 Vp) {
+          constexpr int h = decltype(hc)::value, e = decltype(ec)::value, q = 2 * h + e;
+          u64 mS = 0, mC = 0;
+          if (cl[q] != 0) {
+            const u32 g = Sr[sC][1 + q];
+            const u64 p1m = __ballot(mul16<e, e>(A2, Um) > (int)g), p2m = __ballot(mul16<e, e>(A2, Vp) > (int)g);
+            const u64 k0 = __ballot(max(Sr[sN][1 + q], Sr[sU][1 + q]) <= g);
+            const u64 k1 = __ballot(max(Sr[sN][q], Sr[sU][2 + q]) <= g);
+            const u64 k2 = __ballot(max(Sr[sC][2 + q], Sr[sC][q]) <= g);
+            const u64 k3 = __ballot(max(Sr[sU][q], Sr[sN][2 + q]) <= g);
+            const u64 keep = (~p1m & ~p2m & k0) | (~p1m & p2m & k1) | (p1m & p2m & k2) | (p1m & ~p2m & k3);
+            mS = st[q] & keep;
+            mC = cl[q] & keep;
+          }
+          nibS = shift_in(nibS, mS);
+          nibC = shift_in(nibC, mC);
+        };
+        auto pair = [&](auto hc) {
+          constexpr int h = decltype(hc)::value;
+          const u32 X = Xr[rp][h], Y = Yr[rp][h];
+          const u32 A2 = R(U(X) + U(X));
+          const u32 Um = R(I(X) - I(Y));
+          const u32 Vp = R(U(X) + U(Y));
+          slot(hc, std::integral_constant<int, 1>{}, A2, Um, Vp);
+          slot(hc, std::integral_constant<int, 0>{}, A2, Um, Vp);
+        };
+        pair(std::integral_constant<int, 1>{});
+        pair(std::integral_constant<int, 0>{});
+        nib = (nibS | (nibC << 8)) & oknib;
+      }
+      const u32 w = nib | (from_lane_above(nib) << 4);
+      if (store_lane) {
+        u32 roff;
+        asm("s_mul_i32 %0, %1, %2" : "=s"(roff) : "s"(c), "s"(plane_pitch));
+        u32 so = st_off;
+        asm volatile("" : "+v"(so));
+        (splane + roff)[so] = (uint8_t)w;
+        (cplane + roff)[so] = (uint8_t)(w >> 8);
+      }
+    }
+  };
+
+  // blur rows r0-2 .. rend+1, six per loop trip (the ring period); the next trip's six rows are requested
+  // before this trip's are processed
+  const int k0 = r0 - 2, kend = rend + 2;
+  u32 bn[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) bn[j] = load_b(k0 + j);
+#pragma nounroll
+  for (int k = k0; k < kend; k += 6) {
+    u32 bc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bc[j] = bn[j];
+    if (k + 6 < kend)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) bn[j] = load_b(k + 6 + j);
+    step(std::integral_constant<int, 0>{}, k + 0, bc[0]);
+    step(std::integral_constant<int, 1>{}, k + 1, bc[1]);
+    step(std::integral_constant<int, 2>{}, k + 2, bc[2]);
+    step(std::integral_constant<int, 3>{}, k + 3, bc[3]);
+    step(std::integral_constant<int, 4>{}, k + 4, bc[4]);
+    step(std::integral_constant<int, 5>{}, k + 5, bc[5]);
+  }
+}
+
+template <int IN>
+static hipError_t launch_blur_t(const FrontParams &p, hipStream_t s)
+{
+  hipLaunchKernelGGL((k_blur<IN>), dim3((p.total_items + 3) / 4), dim3(256), (size_t)4 * BLUR_WAVE_BYTES, s, p);
+  return hipGetLastError();
+}
+
+hipError_t launch_blur(const FrontParams &p, hipStream_t s)
+{
+  if (p.run_rows < 1 || p.nchunks * p.run_rows < p.H || !p.blur || p.blur_frame_stride < (size_t)p.nstrips * p.H * 256) return hipErrorInvalidValue;
+  if ((unsigned long long)p.H * p.in_pitch >= (1ull << 32) || (unsigned long long)(p.nstrips + 1) * p.H * 256 >= (1ull << 32)) return hipErrorInvalidValue;
+  return p.bgr == 2 ? launch_blur_t<2>(p, s) : p.bgr == 1 ? launch_blur_t<1>(p, s) : launch_blur_t<0>(p, s);
+}
+
+hipError_t launch_nms(const FrontParams &p, hipStream_t s)
+{
+  if (p.run_rows_b < 1 || p.nchunks_b * p.run_rows_b < p.H || !p.blur) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_nms, dim3((p.total_items_b + 3) / 4), dim3(256), 0, s, p);
+  return hipGetLastError();
 }
 
 // =================================================================================================

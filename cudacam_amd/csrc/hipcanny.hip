@@ -66,6 +66,9 @@ struct hc_ctx {
   int cur = 0;
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
+  int split = 1;        // front path as k_blur + k_nms (default) or the fused k_front
+  uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
+  size_t bplane_fs = 0, bplane_frames = 0;
   int RD = 0;
   int nstrips = 0, chunk = 0, hyst_launches = 6, hyst_waves = 8;
   int last_work_launches = 0, last_continued = 0;
@@ -127,6 +130,26 @@ void free_slot(Slot &s)
   if (s.ev_front) (void)hipEventDestroy(s.ev_front);
   if (s.ev_done) (void)hipEventDestroy(s.ev_done);
   s = Slot{};
+}
+
+// split mode: blur plane [frames][strip][H][256 B] (see canny_kernels.hip); every byte k_nms reads is written by k_blur
+int ensure_blur_plane(hc_ctx *c)
+{
+  const size_t frames = (size_t)c->max_batch * (c->per_channel ? 3 : 1);
+  if (c->d_bplane && c->bplane_frames == frames) return HC_OK;
+  if (c->d_bplane) { (void)hipFree(c->d_bplane); c->d_bplane = nullptr; }
+  c->bplane_fs = (size_t)c->nstrips * c->H * 256;
+  HIPCK(hipMalloc((void **)&c->d_bplane, c->bplane_fs * frames));
+  c->bplane_frames = frames;
+  return HC_OK;
+}
+
+// rows per work item: enough items for a few rounds of the whole chip (8192 resident waves), runs as long as possible
+int pick_run_rows(long units, int H, int want_rows)
+{
+  if (want_rows > 0) return std::min(std::max(want_rows, 2), H);
+  const long nch = std::min<long>(std::max<long>((4 * 8192 + units - 1) / units, 1), std::max(1, H / 16));
+  return (int)((H + nch - 1) / nch);
 }
 
 bool aligned4(const void *p, size_t a, size_t b) { return (((uintptr_t)p | a | b) & 3u) == 0; }
@@ -288,8 +311,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   if (stage == HC_STAGE_HYSTER) {
     FrontParams fp{};
     fp.in = mono; fp.bgr = c->per_channel ? 2 : fuse_bgr ? 1 : 0; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = s.d_sbits; fp.cbits = s.d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
-    // Mode R: a wave marches through `subchunks` sub-chunks of 24 blur rows (run of 24*m - 4 output rows).
-    // Longer runs amortise the 8-row warm-up; shorter runs give more work items (small batches).
+    // Mode R, fused kernel: a wave marches through `subchunks` sub-chunks of 24 blur rows (run of 24*m - 4
+    // output rows).  Longer runs amortise the 8-row warm-up; shorter runs give more work items (small batches).
     int m = c->chunk ? (c->chunk + 4 + 23) / 24 : 0;
     if (m == 0) {
       m = 3;
@@ -298,6 +321,18 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     fp.subchunks = m; fp.run_rows = front_run_rows(m);
     fp.nstrips = c->nstrips; fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows; fp.nframes = n_out;
     fp.total_items = n_out * fp.nstrips * fp.nchunks;
+    const bool split = c->split && c->mode == HC_MODE_R;
+    if (split) {  // k_blur + k_nms through the blur plane
+      if (int rc = ensure_blur_plane(c)) return rc;
+      fp.blur = c->d_bplane; fp.blur_frame_stride = c->bplane_fs;
+      const int rows = pick_run_rows((long)n_out * c->nstrips, H, c->chunk);
+      fp.run_rows = (rows + 1) & ~1;  // k_blur walks rows in pairs
+      fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
+      fp.total_items = n_out * fp.nstrips * fp.nchunks;
+      fp.run_rows_b = rows;
+      fp.nchunks_b = (H + rows - 1) / rows;
+      fp.total_items_b = n_out * fp.nstrips * fp.nchunks_b;
+    }
     if (c->mode == HC_MODE_O) {
       // cv::Canny: plain thresholds on the L1 magnitude; long chunks (no LDS slab, 4-row warm-up)
       fp.a_lo[0] = (u32)c->low; fp.a_hi[0] = (u32)c->high;
@@ -312,7 +347,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);
       band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
       fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
-      HIPCK(launch_front(fp, sf));
+      if (split) {
+        HIPCK(launch_blur(fp, sf));
+        HIPCK(launch_nms(fp, sf));
+      } else HIPCK(launch_front(fp, sf));
     }
     if (prof) HIPCK(hipEventRecord(ev[2], sf));
     if (piped) {
@@ -423,7 +461,7 @@ void hc_destroy(hc_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy }) (void)hipFree(q);
+  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_bplane }) (void)hipFree(q);
   free_slot(c->slot[0]);
   free_slot(c->slot[1]);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
@@ -485,10 +523,13 @@ int hc_set_option(hc_ctx *c, int option, int value)
       (void)hipFree(c->d_out);
       c->d_out = nullptr;
       c->per_channel = value != 0;
+      if (c->d_bplane) { (void)hipFree(c->d_bplane); c->d_bplane = nullptr; c->bplane_frames = 0; }
       if (alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)c->W, c->H, c->max_batch * (c->per_channel ? 3 : 1)) != HC_OK) return HC_E_HIP;
       if (alloc_slot(c, c->slot[0]) != HC_OK) return HC_E_HIP;
       if (had1 && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;
     }
+  } else if (option == HC_OPT_FRONT_SPLIT) {
+    c->split = value != 0;
   } else if (option == HC_OPT_PIPELINE) {
     HIPCK(hipSetDevice(c->device));
     if (value && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;

@@ -124,8 +124,12 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * HC_OPT_PER_CHANNEL (default 0, 3-channel contexts only): 1 = instead of the reference's grey
  * conversion, run the detector on each channel separately (BASELINE config "three-channel,
  * per-channel Canny"): the interleaved input is read once per channel by adjacent work items and
- * every run produces 3 edge maps per input frame, output frame 3*f + ch (ch = byte position in the pixel). */
-enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3 };
+ * every run produces 3 edge maps per input frame, output frame 3*f + ch (ch = byte position in the pixel).
+ *
+ * HC_OPT_FRONT_SPLIT (default 1, Mode R): 1 = the blur and the Sobel/NMS/threshold halves of the fused
+ * path run as two kernels with a u8 blur plane between them (higher occupancy);
+ * 0 = one fused kernel (no intermediate in HBM).  Results are identical. */
+enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* Device self-test of the cross-lane / packed-math primitives the kernels rely on. 0 = ok. */

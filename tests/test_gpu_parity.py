@@ -56,13 +56,32 @@ def test_all_stages_mono(oracle, name, img):
             _diff(got, want[key], f"{name} stage {stage.name}")
 
 
-@pytest.mark.parametrize("chunk", [20, 44, 116, 1080])
-def test_chunk_invariance(oracle, chunk):
+@pytest.mark.parametrize("split", [1, 0])
+@pytest.mark.parametrize("chunk", [7, 20, 44, 116, 1080])
+def test_chunk_invariance(oracle, chunk, split):
+    """Rows per work item (and the one-kernel / two-kernel form of the front path) never change the result."""
     img = synth.natural(700, 333, 11)
     want = oracle.canny_r(img, 10, 40)
     with api.Context(700, 333, 1, 1) as ctx:
+        ctx.set_option(api.OPT_FRONT_SPLIT, split)
         ctx.set_tuning(chunk, 4)
-        _diff(ctx.process(img)[0], want, f"chunk {chunk}")
+        _diff(ctx.process(img)[0], want, f"chunk {chunk} split {split}")
+
+
+@pytest.mark.parametrize("kind", ["noise", "flat", "steps", "natural"])
+def test_fused_front_kernel(oracle, kind):
+    """HC_OPT_FRONT_SPLIT = 0: the single fused kernel (no blur plane) gives the same maps, BGR included."""
+    img = {"noise": lambda: synth.noise(517, 203, 3), "flat": lambda: synth.flat(517, 203, 100),
+           "steps": lambda: synth.steps(517, 203, 90), "natural": lambda: synth.natural(517, 203, 3)}[kind]()
+    want = oracle.canny_r(img, 10, 40)
+    with api.Context(517, 203, 1, 1) as ctx:
+        ctx.set_option(api.OPT_FRONT_SPLIT, 0)
+        _diff(ctx.process(img)[0], want, f"fused {kind}")
+    rng = np.random.default_rng(17)
+    bgr = rng.integers(0, 256, (90, 260, 3), dtype=np.uint8)
+    with api.Context(260, 90, 3, 1) as ctx:
+        ctx.set_option(api.OPT_FRONT_SPLIT, 0)
+        _diff(ctx.process(bgr)[0], oracle.canny_r(bgr, 10, 40), "fused bgr")
 
 
 def test_bgr_input(oracle):
