@@ -36,7 +36,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU (2 GiB in + 2 GiB out at 1080p; hysteresis is latency-bound, larger batches amortise it)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
     ap.add_argument("--chunk", type=int, default=0)

@@ -903,12 +903,14 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
           u64 mS = 0, mC = 0;
           if (cl[q] != 0) {
             const u32 g = Sr[sC][1 + q];
-            const u64 p1m = __ballot(mul16<e, e>(A2, Um) > (int)g), p2m = __ballot(mul16<e, e>(A2, Vp) > (int)g);
-            const u64 k0 = __ballot(max(Sr[sN][1 + q], Sr[sU][1 + q]) <= g);
-            const u64 k1 = __ballot(max(Sr[sN][q], Sr[sU][2 + q]) <= g);
-            const u64 k2 = __ballot(max(Sr[sC][2 + q], Sr[sC][q]) <= g);
-            const u64 k3 = __ballot(max(Sr[sU][q], Sr[sN][2 + q]) <= g);
-            const u64 keep = (~p1m & ~p2m & k0) | (~p1m & p2m & k1) | (p1m & p2m & k2) | (p1m & ~p2m & k3);
+            const bool p1 = mul16<e, e>(A2, Um) > (int)g, p2 = mul16<e, e>(A2, Vp) > (int)g;
+            // the larger neighbour of each of the 4 directions (cannyEdgeD.cu:245-264: bin0 down/up, bin1
+            // down-left/up-right, bin2 right/left, bin3 up-left/down-right), then the one of this pixel's bin.
+            // All per lane on the VALU: the scalar unit, shared by the CU's 4 SIMDs, is as loaded as the VALU here.
+            const u32 m0 = max(Sr[sN][1 + q], Sr[sU][1 + q]), m1 = max(Sr[sN][q], Sr[sU][2 + q]);
+            const u32 m2 = max(Sr[sC][2 + q], Sr[sC][q]), m3 = max(Sr[sU][q], Sr[sN][2 + q]);
+            const u32 mb = p1 ? (p2 ? m2 : m3) : (p2 ? m1 : m0);
+            const u64 keep = __ballot(mb <= g);  // non-strict on both sides
             mS = st[q] & keep;
             mC = cl[q] & keep;
           }
