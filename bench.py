@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
     ap.add_argument("--fused", action="store_true", help="HC_OPT_FRONT_SPLIT = 0: the single fused front kernel instead of k_blur + k_nms")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
+    ap.add_argument("--channels", type=int, default=1, choices=[1, 3], help="3: interleaved BGR input (grey conversion fused into the load)")
+    ap.add_argument("--per-channel", action="store_true", help="with --channels 3: one edge map per channel (BASELINE configs[4])")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -75,14 +77,24 @@ def main():
     B = a.batch
     f0, f1 = shard.frame_range(B * world, rank, world)   # this rank's block of every step's frame stream
     assert f1 - f0 == B
-    uniq = synth.frames(a.kind, W, H, min(a.unique, B), seed=synth.SEED0 + 1000 * rank)
-    d_u = torch.from_numpy(uniq).to(dev)
+    C = a.channels
+    if C == 3 and (a.mode != "R" or W % 4):
+        raise SystemExit("--channels 3 needs mode R and a width that is a multiple of 4 (whole 12-byte pixel groups)")
+    nu = min(a.unique, B)
+    if C == 1:
+        uniq = synth.frames(a.kind, W, H, nu, seed=synth.SEED0 + 1000 * rank)
+    else:   # three differently seeded planes interleaved as B, G, R
+        uniq = np.stack([synth.frames(a.kind, W, H, nu, seed=synth.SEED0 + 1000 * rank + 77 * c) for c in range(3)], axis=-1)
+    d_u = torch.from_numpy(np.ascontiguousarray(uniq)).to(dev)
     reps = (B + d_u.shape[0] - 1) // d_u.shape[0]
-    d_in = d_u.repeat(reps, 1, 1)[:B].contiguous()          # (B, H, W) u8, tight pitch 1920
-    d_out = torch.empty_like(d_in)
+    d_in = d_u.repeat(*([reps] + [1] * (d_u.dim() - 1)))[:B].contiguous()   # (B, H, W[, 3]) u8, tight pitch
+    n_out = 3 * B if a.per_channel else B
+    d_out = torch.empty((n_out, H, W), dtype=torch.uint8, device=dev)
     del d_u
 
-    ctx = api.Context(W, H, 1, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local)
+    ctx = api.Context(W, H, C, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local)
+    if a.per_channel:
+        ctx.set_option(api.OPT_PER_CHANNEL, 1)
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
     ctx.set_option(api.OPT_PIPELINE, 0 if a.no_pipeline else 1)
@@ -92,7 +104,7 @@ def main():
     ctx.set_stream(stream.cuda_stream)
 
     def step():
-        ctx.run_device(d_in.data_ptr(), W, W * H, d_out.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
+        ctx.run_device(d_in.data_ptr(), W * C, W * C * H, d_out.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
 
     for _ in range(a.warmup):
         step()
@@ -120,12 +132,13 @@ def main():
     if rank == 0:
         frames_total = B * a.steps * world
         fps = frames_total / elapsed
-        alg_bytes_per_launch = 2.0 * W * H * B                      # 2*W*H per mono frame
+        alg_bytes_per_frame = float(W * H * C + W * H * (3 if a.per_channel else 1))   # 2*W*H per mono frame
+        alg_bytes_per_launch = alg_bytes_per_frame * B
         front_ms = sums[1] / max(nruns, 1)
         hyst_ms = sums[2] / max(nruns, 1)
         achieved = alg_bytes_per_launch / (front_ms * 1e-3) / 1e9 if front_ms > 0 else 0.0
         out = {
-            "metric": f"frames/sec, {W}x{H} grayscale Canny (" + ("5-stage, Mode R" if a.mode == "R" else "cv::Canny semantics, Mode O") + ", device-resident)",
+            "metric": f"frames/sec, {W}x{H} " + ("grayscale" if C == 1 else "3-channel per-channel" if a.per_channel else "BGR") + " Canny (" + ("5-stage, Mode R" if a.mode == "R" else "cv::Canny semantics, Mode O") + ", device-resident)",
             "value": round(fps, 1),
             "unit": "frames/s",
             "n_gpus": world,
@@ -139,10 +152,10 @@ def main():
             "dtype": "u8",
             "data": f"synthetic ({a.kind}, {min(a.unique, B)} distinct frames tiled to the batch)",
             "config": {"workload": (f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU" if (W, H, a.mode) == (1920, 1080, "R")
-                                    else f"{W}x{H} grayscale, mode {a.mode}, batch {B} frames/step/GPU"),
+                                    else f"{W}x{H} " + ("grayscale" if C == 1 else "BGR, per-channel Canny" if a.per_channel else "BGR -> grey") + f", mode {a.mode}, batch {B} frames/step/GPU"),
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",
                        "pipeline": not a.no_pipeline},
-            "e2e_alg_GBps": round(2.0 * W * H * frames_total / elapsed / 1e9, 1),
+            "e2e_alg_GBps": round(alg_bytes_per_frame * frames_total / elapsed / 1e9, 1),
             "roofline": {
                 "bound": "hbm", "kernel": ("k_front" if a.fused else "k_blur+k_nms") if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(achieved / HBM_MEASURED_COPY_GBPS, 4),
@@ -150,7 +163,7 @@ def main():
             },
             "hysteresis": {"launches_with_work": work_launches, "continued": continued},
         }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and C == 1:
             out["cpu_baseline"] = cpu_baseline(a, d_in, d_out)
         print(json.dumps(out), flush=True)
     ctx.close()

@@ -1655,7 +1655,7 @@ __global__ void k_graddisp(const int16_t *sx, const int16_t *sy, size_t sp, size
   out[f * ofs + row * op + col] = (uint8_t)min(g, 255u);
 }
 
-__global__ void k_nms(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int saturate)
+__global__ void k_nms_tap(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int saturate)
 {
   PIX_PROLOG
   const int16_t *X = sx + f * sfs, *Y = sy + f * sfs;
@@ -1698,7 +1698,7 @@ hipError_t launch_sobel(const uint8_t *blur, size_t bpitch, size_t bfs, int16_t 
 hipError_t launch_graddisp(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int n, hipStream_t s)
 { PIX_GRID; hipLaunchKernelGGL(k_graddisp, grd, blk, 0, s, sx, sy, sp, sfs, out, op, ofs, W, H); return hipGetLastError(); }
 hipError_t launch_nms(const int16_t *sx, const int16_t *sy, size_t sp, size_t sfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int n, int saturate, hipStream_t s)
-{ PIX_GRID; hipLaunchKernelGGL(k_nms, grd, blk, 0, s, sx, sy, sp, sfs, out, op, ofs, W, H, saturate); return hipGetLastError(); }
+{ PIX_GRID; hipLaunchKernelGGL(k_nms_tap, grd, blk, 0, s, sx, sy, sp, sfs, out, op, ofs, W, H, saturate); return hipGetLastError(); }
 hipError_t launch_thresh(const uint8_t *nms, size_t np, size_t nfs, uint8_t *out, size_t op, size_t ofs, int W, int H, int n, int low, int high, hipStream_t s)
 { PIX_GRID; hipLaunchKernelGGL(k_thresh, grd, blk, 0, s, nms, np, nfs, out, op, ofs, W, H, low, high); return hipGetLastError(); }
 

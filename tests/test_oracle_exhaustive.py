@@ -29,6 +29,19 @@ def test_div159_magic():
     S = np.arange(0, 159 * 255 + 1, dtype=np.uint64)
     assert np.array_equal((S * np.uint64(52759)) >> np.uint64(23), S // np.uint64(159))
     assert int(S[-1]) * 52759 < 2 ** 31
+    # k_blur's undecidable-pixel test: S % 159 == 0  <=>  bits 15..22 of S*52759 are all zero (the byte below the
+    # quotient byte after >> 15), and the byte-wise zero detector never misses one (it may over-flag, which is harmless)
+    P = S * np.uint64(52759)
+    frac_byte = (P >> np.uint64(15)) & np.uint64(0xFF)
+    assert np.array_equal(frac_byte == 0, S % np.uint64(159) == 0)
+    rng = np.random.default_rng(3)
+    x = rng.integers(0, 2 ** 32, 2_000_000, dtype=np.uint64)
+    x[: 4 * 65536] = (rng.integers(0, 256, (65536, 4), dtype=np.uint64) * np.array([1, 0, 1, 1], dtype=np.uint64) << np.array([0, 8, 16, 24], dtype=np.uint64)).sum(1).repeat(4)
+    hz = ((x - np.uint64(0x01010101)) & ~x & np.uint64(0x80808080)) & np.uint64(0xFFFFFFFF)
+    for b in range(4):
+        is_zero = ((x >> np.uint64(8 * b)) & np.uint64(0xFF)) == 0
+        flagged = (hz >> np.uint64(8 * b + 7)) & np.uint64(1)
+        assert np.all(flagged[is_zero] == 1)
 
 
 def test_gaussian_shortcut_random_patches(oracle):
