@@ -40,7 +40,7 @@ def parse():
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
     ap.add_argument("--chunk", type=int, default=0)
-    ap.add_argument("--hyst-launches", type=int, default=6)
+    ap.add_argument("--hyst-launches", type=int, default=0, help="hysteresis launches queued per run (0 = auto)")
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
     ap.add_argument("--fused", action="store_true", help="HC_OPT_FRONT_SPLIT = 0: the single fused front kernel instead of k_blur + k_nms")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")

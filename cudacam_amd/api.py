@@ -154,7 +154,7 @@ class Context:
         _ck(self.lib.hc_get_thresholds(self.handle, C.byref(lo), C.byref(hi)))
         return lo.value, hi.value
 
-    def set_tuning(self, chunk_rows=0, hyst_launches=4):
+    def set_tuning(self, chunk_rows=0, hyst_launches=0):
         _ck(self.lib.hc_set_tuning(self.handle, int(chunk_rows), int(hyst_launches)))
 
     def set_option(self, option, value):

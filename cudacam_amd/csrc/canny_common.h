@@ -64,14 +64,6 @@ struct HystParams {
   int first_pass;  // the planes come straight from k_front / k_pack: rows are not yet closed under the in-row fill
 };
 
-struct ExpandParams {
-  const u32 *sbits;
-  int RD;
-  uint8_t *out;
-  size_t out_pitch, out_frame_stride;
-  int W, H, nframes;
-};
-
 struct PackParams {  // tri-state u8 map (0/128/255) -> bit planes
   const uint8_t *in;
   size_t in_pitch, in_frame_stride;
@@ -87,7 +79,6 @@ hipError_t launch_front_o(const FrontParams &p, hipStream_t s);
 hipError_t launch_blur(const FrontParams &p, hipStream_t s);
 hipError_t launch_nms(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);
-hipError_t launch_expand(const ExpandParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
 size_t front_lds_bytes();
 int front_run_rows(int subchunks);

@@ -2,9 +2,9 @@
 //
 // What the reference does in 9+k launches over 25 B/px of intermediates (src/cvp/cannyEdgeD.cu,
 // launch sites src/cvp/cannyEdgeH.cu:214-338) is done here in
-//   k_front   blur + Sobel + magnitude + direction + NMS + double threshold, one pass, output = 2 bit planes
-//   k_hyst    edge hysteresis on the bit planes (64 px per 64-bit op), device-side convergence flag
-//   k_expand  bit plane -> 0/255 u8 edge map
+//   k_blur + k_nms (or the fused k_front)   blur | Sobel + magnitude + direction + NMS + double threshold -> 2 bit planes
+//   k_hyst    edge hysteresis on the bit planes (64 px per 64-bit op), device-side convergence flag,
+//             0/255 u8 edge map written by the same kernel
 // MFMA is deliberately not used: there is no dense contraction (an f32 MFMA would reproduce the
 // Gaussian's fmaf chain bit for bit, but as a banded 36x32 Toeplitz product it wastes 31/36 of its
 // multiplies and runs at the f32 vector rate -- 4-7x slower than the packed integer form below).
@@ -561,10 +561,7 @@ template <int IN>
 static hipError_t launch_front_t(const FrontParams &p, hipStream_t s)
 {
   const int nblocks = (p.total_items + 3) / 4;
-  size_t lds = front_lds_bytes();
-  static const int lds_pad = getenv("HC_FRONT_LDS") ? atoi(getenv("HC_FRONT_LDS")) : 0;  // experiments: occupancy cap via LDS
-  if (lds_pad > (int)lds && lds_pad <= 65536) lds = (size_t)lds_pad;
-  hipLaunchKernelGGL((k_front<IN>), dim3(nblocks), dim3(256), lds, s, p);
+  hipLaunchKernelGGL((k_front<IN>), dim3(nblocks), dim3(256), front_lds_bytes(), s, p);
   return hipGetLastError();
 }
 
@@ -1557,49 +1554,6 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   else if (g.nw == 1 && g.tr == 32 && g.waves == 16) hipLaunchKernelGGL((k_hyst<1, 32, 16>), grid, block, 0, s, p);
   else if (g.nw == 2) hipLaunchKernelGGL((k_hyst<2, 32, 8>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((k_hyst<4, 16, 8>), grid, block, 0, s, p);
-  return hipGetLastError();
-}
-
-// =================================================================================================
-// k_expand: strong plane -> u8 edge map (255 / 0); candidates left over are dropped here
-// (removeCandidates, cannyEdgeD.cu:379-395).  16 px per lane: one ushort of bits -> one 16-byte store.
-// =================================================================================================
-template <bool ALIGN16>
-__global__ __launch_bounds__(256) void k_expand(const ExpandParams p)
-{
-  const int lane = threadIdx.x & 63;
-  const int segs = (p.W + 1023) / 1024;  // 1024 px (64 lanes x 16) per wave
-  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long total = (long long)p.nframes * p.H * segs;
-  if (wave >= total) return;
-  const int seg = (int)(wave % segs);
-  const int row = (int)((wave / segs) % p.H);
-  const int frame = (int)(wave / ((long long)segs * p.H));
-  const int c0 = seg * 1024 + lane * 16;
-  if (c0 >= p.W) return;
-  const unsigned short *bits = reinterpret_cast<const unsigned short *>(p.sbits + ((size_t)frame * p.H + row) * p.RD);
-  const u32 b = bits[c0 >> 4];
-  uint8_t *dst = p.out + (size_t)frame * p.out_frame_stride + (size_t)row * p.out_pitch + c0;
-  u32 v[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
-  if (c0 + 15 < p.W) {
-    if (ALIGN16) *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
-    else
-#pragma unroll
-      for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
-  } else {
-    for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
-  }
-}
-
-hipError_t launch_expand(const ExpandParams &p, hipStream_t s)
-{
-  const long long total = (long long)p.nframes * p.H * ((p.W + 1023) / 1024);
-  const dim3 grid((unsigned)((total + 3) / 4)), block(256);
-  const bool a16 = (((uintptr_t)p.out | p.out_pitch | p.out_frame_stride) & 15u) == 0;
-  if (a16) hipLaunchKernelGGL(k_expand<true>, grid, block, 0, s, p);
-  else hipLaunchKernelGGL(k_expand<false>, grid, block, 0, s, p);
   return hipGetLastError();
 }
 

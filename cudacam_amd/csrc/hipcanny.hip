@@ -40,10 +40,10 @@ struct Slot {
   hipEvent_t ev_front = nullptr, ev_done = nullptr;  // front kernel finished / hysteresis + expand finished
   bool pending = false;                              // convergence flag not yet checked by the host
   HystParams ph{};
-  ExpandParams pe{};
   void *copy_dst = nullptr;  // caller buffer when the expand went to the internal one
   size_t copy_pitch = 0, copy_fs = 0;
   int n = 0;
+  int k_launches = 0;            // hysteresis launches queued for this run
   hipStream_t stream = nullptr;  // stream the hysteresis of this run was queued on
 };
 }  // namespace
@@ -71,6 +71,7 @@ struct hc_ctx {
   size_t bplane_fs = 0, bplane_frames = 0;
   int RD = 0;
   int nstrips = 0, chunk = 0, hyst_launches = 6, hyst_waves = 8;
+  bool hyst_launches_set = false;  // hc_set_tuning called: queue exactly that many launches
   int last_work_launches = 0, last_continued = 0;
   u32 h_stats[3 * 16] = { 0 };
   int uploaded = 0, last_run_n = 0;
@@ -186,7 +187,7 @@ int finish_slot(hc_ctx *c, Slot &s)
   s.pending = false;
   hipStream_t st = s.stream;
   HIPCK(hipEventSynchronize(s.ev_done));
-  const int K = c->hyst_launches;
+  const int K = s.k_launches;
   int work = 0;
   for (int k = 0; k < K; ++k) work += s.h_flags[k] != 0;
   std::memcpy(c->h_stats, s.h_flags + MAX_HYST_LAUNCHES, sizeof(c->h_stats));
@@ -209,7 +210,7 @@ int finish_slot(hc_ctx *c, Slot &s)
     if (s.h_flags[K - 1] == 0) break;
   }
   if (s.copy_dst)
-    if (int rc = copy_frames_d2d(c, st, s.copy_dst, s.copy_pitch, s.copy_fs, s.pe.out, s.pe.out_pitch, s.pe.out_frame_stride, (size_t)c->W, s.n)) return rc;
+    if (int rc = copy_frames_d2d(c, st, s.copy_dst, s.copy_pitch, s.copy_fs, s.ph.out, s.ph.out_pitch, s.ph.out_frame_stride, (size_t)c->W, s.n)) return rc;
   HIPCK(hipStreamSynchronize(st));
   return HC_OK;
 }
@@ -224,13 +225,15 @@ int finish_all(hc_ctx *c)
 // bit planes of slot s -> fixpoint -> u8 image, queued on `st`
 int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t out_pitch, size_t out_fs, int n, bool small_tiles)
 {
-  const int K = c->hyst_launches;
   HystParams hp{};
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags; hp.tflags = s.d_tflags;
   // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
   hyst_tile_geometry(c->RD, &hp.tile_rows, &hp.waves);
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
   (void)small_tiles;
+  // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
+  // tall frame (later launches exit at once after convergence; beyond the queue, hc_sync continues from the host)
+  const int K = c->hyst_launches_set ? c->hyst_launches : std::min(MAX_HYST_LAUNCHES, std::max(c->hyst_launches, hp.nrtiles + 1));
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
   hp.debug_skip = getenv("HC_DEBUG_SKIP_HYST") ? 1 : 0;
@@ -240,12 +243,10 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
     hp.stats = getenv("HC_HYST_DIAG") ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
     HIPCK(launch_hyst(hp, st));
   }
-  ExpandParams ep{};  // (kept for the copy-out bookkeeping; the expand itself is fused into k_hyst)
-  ep.sbits = s.d_sbits; ep.RD = c->RD; ep.out = out; ep.out_pitch = out_pitch; ep.out_frame_stride = out_fs; ep.W = c->W; ep.H = c->H; ep.nframes = n;
   HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, st));
   s.pending = true;
+  s.k_launches = K;
   s.ph = hp;
-  s.pe = ep;
   s.n = n;
   s.stream = st;
   s.copy_dst = nullptr;
@@ -431,7 +432,6 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     // priority their workgroups are placed ahead of the next run's 30k-wave front kernel instead of behind it
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (getenv("HC_NO_STREAM_PRIORITY")) greatest = least;
     good = good && ok(hipStreamCreateWithPriority(&c->s_hyst, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
   }
   good = good && ok(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming), "hipEventCreate");
@@ -501,9 +501,11 @@ int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
 {
   if (!c) return fail(HC_E_ARG, "null context");
   if (chunk_rows < 0 || chunk_rows > 16384) return fail(HC_E_ARG, "chunk_rows must be 0 (auto) or 1..16384");
-  if (hyst_launches < 1 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range");
+  if (hyst_launches < 0 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range (0 = auto, 1..16)");
   if (int rc = finish_all(c)) return rc;
-  c->chunk = chunk_rows; c->hyst_launches = hyst_launches;
+  c->chunk = chunk_rows;
+  c->hyst_launches_set = hyst_launches != 0;
+  c->hyst_launches = hyst_launches ? hyst_launches : 6;
   return HC_OK;
 }
 
