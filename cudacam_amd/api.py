@@ -43,6 +43,7 @@ OPT_NMS_SATURATE = 1
 OPT_PIPELINE = 2
 OPT_PER_CHANNEL = 3
 OPT_FRONT_SPLIT = 4
+OPT_L2_GRADIENT = 5
 
 # every symbol include/hipcanny.h declares
 ABI_SYMBOLS = [

@@ -34,6 +34,7 @@ struct FrontParams {
   int subchunks;   // Mode R kernel: sub-chunks of 24 blur rows a wave marches through per work item
   int run_rows;    // = 24 * subchunks - 4 output rows per work item; nchunks = ceil(H / run_rows)
   int chunk_rows;          // Mode O kernel: output rows per work item (any value >= 1)
+  int l2gradient;          // Mode O kernel: magnitude dx^2 + dy^2 instead of |dx| + |dy| (cv::Canny's L2gradient)
   int total_items;         // nframes * nstrips * nchunks
   // thresholds on S = sumX^2 + sumY^2 for "u8-wrapped gradient > T" (band test)
   u32 a_lo[3], a_hi[3];

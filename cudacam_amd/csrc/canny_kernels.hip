@@ -984,15 +984,16 @@ hipError_t launch_nms(const FrontParams &p, hipStream_t s)
 }
 
 // =================================================================================================
-// k_front_o: "Mode O" -- cv::Canny(src 8UC1, low, high, apertureSize 3, L2gradient false) semantics
+// k_front_o: "Mode O" -- cv::Canny(src 8UC1, low, high, apertureSize 3, L2gradient) semantics
 // =================================================================================================
 // OpenCV 4.x modules/imgproc/src/canny.cpp (the parity tests check it against a CPU restatement): no blur,
-// Sobel 3x3 on the source with BORDER_REPLICATE, L1 magnitude m = |dx|+|dy| (0 outside the image),
-// pixels with m <= low are dropped, direction by the integer tangent test (TG22 = 13573, shift 15),
-// asymmetric non-maximum suppression (m > first neighbour, m >= second on the axes; strict on both
-// diagonal neighbours), m > high seeds.  Same strip / lane / DPP layout and the same bit-plane
-// output as k_front, so k_hyst finishes the job.  One pass, registers only (no LDS): a work item is
+// Sobel 3x3 on the source with BORDER_REPLICATE, magnitude m = |dx|+|dy| (or dx^2+dy^2 with L2gradient; 0
+// outside the image), pixels with m <= low are dropped, direction by the integer tangent test
+// (TG22 = 13573, shift 15), asymmetric non-maximum suppression (m > first neighbour, m >= second on the
+// axes; strict on both diagonal neighbours), m > high seeds.  Same strip / lane / DPP layout and the same
+// bit-plane output as k_nms, so k_hyst finishes the job.  One pass, registers only (no LDS): a work item is
 // (frame, strip, chunk of p.chunk_rows rows) with a 4-row warm-up.
+template <bool L2>
 __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
 {
   const int lane = threadIdx.x & 63;
@@ -1021,131 +1022,155 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
   const u32 pm0 = __builtin_amdgcn_perm(0u, cmask, 0x01010000u), pm1 = __builtin_amdgcn_perm(0u, cmask, 0x03030202u);
   const u32 oknib1 = (lane >= 1 && lane <= 62) ? ((cmask & 1u) | ((cmask >> 7) & 2u) | ((cmask >> 14) & 4u) | ((cmask >> 21) & 8u)) : 0u;
   const u32 oknib = oknib1 | (oknib1 << 8);
-  const uint8_t *src = p.in + (size_t)frame * p.in_frame_stride + ld_col;
+  const uint8_t *fbase = p.in + (size_t)frame * p.in_frame_stride;  // wave-uniform
+  const u32 in_pitch32 = (u32)p.in_pitch;                            // launch_front_o checks H * pitch < 2^32
+  const u32 ld_off = (u32)ld_col;
   auto load_row = [&](int row) -> u32 {  // BORDER_REPLICATE along the column: clamp the row
     const int rr = min(max(row, 0), H - 1);
-    return __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32 *>(src + (size_t)rr * p.in_pitch), rsel);
+    u32 roff;
+    asm("s_mul_i32 %0, %1, %2" : "=s"(roff) : "s"(rr), "s"(in_pitch32));
+    u32 o = ld_off;
+    asm volatile("" : "+v"(o));  // scalar row base + 32-bit lane offset
+    return __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32 *>(fbase + roff + o), rsel);
   };
 
   u32 dr[2][2], sr[2][2];  // d = x[+1]-x[-1] and s = x[-1]+2x[0]+x[+1] of the two previous rows, [ring][pair]
   u32 Mr[3][6];            // magnitude rows: [ring][0]=left neighbour, [1..4]=own 4 px, [5]=right neighbour
-  u32 Vr[2][4];            // packed (dx,dy) of the two newest gradient rows
+  u32 Xr[2][2], Yr[2][2];  // packed dx / dy pairs of the two newest gradient rows
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) dr[a][b] = sr[a][b] = 0;
+    for (int b = 0; b < 2; ++b) dr[a][b] = sr[a][b] = Xr[a][b] = Yr[a][b] = 0;
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int b = 0; b < 6; ++b) Mr[a][b] = 0;
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) Vr[a][b] = 0;
-  const size_t plane_off = (size_t)frame * H * p.RD * 4 + (size_t)strip * 31 + (size_t)((lane - 1) >> 1);
-  uint8_t *srow = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
-  uint8_t *crow = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
+  const size_t plane_off = (size_t)frame * H * p.RD * 4;
+  uint8_t *splane = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
+  uint8_t *cplane = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
   const bool store_lane = (lane & 1) && lane < 63;
+  const u32 st_off = (u32)(strip * 31 + (lane >> 1));
+  const u32 plane_pitch = (u32)p.RD * 4u;
   const u32 low = p.a_lo[0], high = p.a_hi[0];  // Mode O: plain thresholds on m
+  const u32 k_tg22 = 13573u, k_m32768 = 0x8000u;  // 16-bit multiplier operands (low halves): TG22 and -2^15
 
-  // step t: source row k = r0 - 2 + t arrives; gradient row i = k - 1; NMS row c = k - 2
-  const int nsteps = (rend - r0) + 4;
-  constexpr int G = 6;
-  u32 xn[G];
+  // one step: source row k arrives -> gradient row k-1 -> NMS / threshold row k-2
+  auto step = [&](auto uc, int k, u32 b) {
+    constexpr int u = decltype(uc)::value;
+    constexpr int rn = u % 2, rp = (u + 1) % 2;
+    constexpr int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;
+    const u32 A = unpack_lo(b), B = unpack_hi(b);
+    const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
+    const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
+    u32 dk[2], sk[2];
+    dk[0] = R(I(p1) - I(m1));
+    sk[0] = pk_mad2(A, m1 + p1);
+    dk[1] = R(I(p3) - I(p1));
+    sk[1] = pk_mad2(B, p1 + p3);
+    const int i = k - 1;  // gradient row from source rows k-2 (ring rn), k-1 (ring rp), k (new)
+    const u32 rowm = (i >= 0 && i < H) ? 0xFFFFFFFFu : 0u;  // magnitude outside the image is 0
 #pragma unroll
-  for (int j = 0; j < G; ++j) xn[j] = load_row(r0 - 2 + j);
-#pragma nounroll
-  for (int t0 = 0; t0 < nsteps; t0 += G) {
-    u32 xc[G];
-#pragma unroll
-    for (int j = 0; j < G; ++j) xc[j] = xn[j];
-    if (t0 + G < nsteps)
-#pragma unroll
-      for (int j = 0; j < G; ++j) xn[j] = load_row(r0 - 2 + t0 + G + j);
-#pragma unroll
-    for (int u = 0; u < G; ++u) {
-      const int t = t0 + u;
-      if (t >= nsteps) break;
-      const int k = r0 - 2 + t;
-      const int rn = u % 2, rp = (u + 1) % 2;
-      const int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;
-      const u32 b = xc[u];
-      const u32 A = unpack_lo(b), B = unpack_hi(b);
-      const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
-      const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
-      u32 dk[2], sk[2];
-      dk[0] = R(I(p1) - I(m1));
-      sk[0] = pk_mad2(A, m1 + p1);
-      dk[1] = R(I(p3) - I(p1));
-      sk[1] = pk_mad2(B, p1 + p3);
-      const int i = k - 1;  // gradient row from source rows k-2 (ring rn), k-1 (ring rp), k (new)
-      if (i >= 0 && i < H) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const u32 pm = h == 0 ? pm0 : pm1;  // magnitude outside the image is 0
-          const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;  // dx = right - left, smoothed 1-2-1 down the rows
-          const u32 Y = R(I(sk[h]) - I(sr[rn][h])) & pm;                       // dy = bottom - top
-          Vr[rn][2 * h + 0] = __builtin_amdgcn_perm(Y, X, 0x05040100u);
-          Vr[rn][2 * h + 1] = __builtin_amdgcn_perm(Y, X, 0x07060302u);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const i16x2 v = I(Vr[rn][q]);
-          const u32 av = R(__builtin_elementwise_max(v, -v));                // (|dx|, |dy|)
-          Mr[sN][1 + q] = __builtin_amdgcn_udot2(U(av), U(0x00010001u), 0u, false);  // L1 magnitude
-        }
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) { Mr[sN][1 + q] = 0; Vr[rn][q] = 0; }
+    for (int h = 0; h < 2; ++h) {
+      const u32 pm = (h == 0 ? pm0 : pm1) & rowm;
+      const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;  // dx = right - left, smoothed 1-2-1 down the rows
+      const u32 Y = R(I(sk[h]) - I(sr[rn][h])) & pm;                       // dy = bottom - top
+      Xr[rn][h] = X;
+      Yr[rn][h] = Y;
+      if (L2) {
+        Mr[sN][1 + 2 * h] = (u32)mad16<0, 0>(X, X, mul16<0, 0>(Y, Y));
+        Mr[sN][2 + 2 * h] = (u32)mad16<1, 1>(X, X, mul16<1, 1>(Y, Y));
+      } else {  // |dx| + |dy| <= 2040 per half: packed, then split
+        const u32 mp = R(__builtin_elementwise_max(I(X), -I(X))) + R(__builtin_elementwise_max(I(Y), -I(Y)));
+        Mr[sN][1 + 2 * h] = mp & 0xFFFFu;
+        Mr[sN][2 + 2 * h] = mp >> 16;
       }
-      Mr[sN][0] = from_lane_below(Mr[sN][4]);
-      Mr[sN][5] = from_lane_above(Mr[sN][1]);
+    }
+    Mr[sN][0] = from_lane_below(Mr[sN][4]);
+    Mr[sN][5] = from_lane_above(Mr[sN][1]);
 #pragma unroll
-      for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
+    for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
 
-      const int c = k - 2;
-      if (c >= r0 && c < rend) {
-        u32 nib = 0;
-        const u32 mx = max(max(Mr[sC][1], Mr[sC][2]), max(Mr[sC][3], Mr[sC][4]));
-        if (__ballot(mx > low) != 0) {
+    const int c = k - 2;
+    if (c >= r0 && c < rend) {
+      u32 nib = 0;
+      u64 cl[4];
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 4; ++q) cl[q] = __ballot(Mr[sC][1 + q] > low);
+      if ((cl[0] | cl[1] | cl[2] | cl[3]) != 0) {  // rows without a candidate skip direction + NMS
+        u32 nibS = 0, nibC = 0;
+        auto slot = [&](auto hc, auto ec, u32 aX, u32 aY, u32 X, u32 Y) {
+          constexpr int h = decltype(hc)::value, e = decltype(ec)::value, q = 2 * h + e;
+          u64 mS = 0, mC = 0;
+          if (cl[q] != 0) {
             const u32 m = Mr[sC][1 + q];
-            const u64 cl = __ballot(m > low), st = __ballot(m > high);
-            if (cl == 0) continue;
-            const u32 V = Vr[rp][q];
-            const i16x2 v = I(V);
-            const u32 av = R(__builtin_elementwise_max(v, -v));
-            const u32 x = av & 0xFFFFu, y = av >> 16;
-            const u32 tg22 = x * 13573u, ysh = y << 15;
-            const u32 tg67 = tg22 + (x << 16);
-            const u64 hz = __ballot(ysh < tg22), vt = __ballot(ysh > tg67);
-            const u64 dneg = __ballot((int)(V ^ (V << 16)) < 0);  // sign(dx) != sign(dy)
+            // tangent test on x = |dx|, y = |dy|: horizontal if y*2^15 < x*TG22, vertical if y*2^15 > x*(TG22 + 2^16)
+            const int E = mad16<e, 0>(aY, k_m32768, mul16<e, 0>(aX, k_tg22));  // x*TG22 - y*2^15
+            const int x16 = (int)(e ? (aX & 0xFFFF0000u) : (aX << 16));          // x * 2^16
+            const u64 hz = __ballot(E > 0), vt = __ballot(E + x16 < 0);
+            const u64 dneg = __ballot(mul16<e, e>(X, Y) < 0);  // sign(dx) != sign(dy) (both non-zero on a diagonal)
             const u64 kh = __ballot(m > Mr[sC][q]) & __ballot(m >= Mr[sC][2 + q]);       // left, right
             const u64 kv = __ballot(m > Mr[sU][1 + q]) & __ballot(m >= Mr[sN][1 + q]);   // up, down
             const u64 kp = __ballot(m > Mr[sU][q]) & __ballot(m > Mr[sN][2 + q]);        // s = +1: up-left, down-right
             const u64 kn = __ballot(m > Mr[sU][2 + q]) & __ballot(m > Mr[sN][q]);        // s = -1: up-right, down-left
             const u64 dg = ~hz & ~vt;
             const u64 keep = (hz & kh) | (~hz & vt & kv) | (dg & ~dneg & kp) | (dg & dneg & kn);
-            nib |= __builtin_amdgcn_inverse_ballot_w64(st & keep) ? (1u << q) : 0u;
-            nib |= __builtin_amdgcn_inverse_ballot_w64(cl & keep) ? (0x100u << q) : 0u;
+            mS = __ballot(m > high) & keep;
+            mC = cl[q] & keep;
           }
-          nib &= oknib;
-        }
-        const u32 w = nib | (from_lane_above(nib) << 4);
-        if (store_lane) {
-          srow[(size_t)c * p.RD * 4] = (uint8_t)w;
-          crow[(size_t)c * p.RD * 4] = (uint8_t)(w >> 8);
-        }
+          nibS = shift_in(nibS, mS);
+          nibC = shift_in(nibC, mC);
+        };
+        auto pair = [&](auto hc) {
+          constexpr int h = decltype(hc)::value;
+          const u32 X = Xr[rp][h], Y = Yr[rp][h];
+          const u32 aX = R(__builtin_elementwise_max(I(X), -I(X))), aY = R(__builtin_elementwise_max(I(Y), -I(Y)));
+          slot(hc, std::integral_constant<int, 1>{}, aX, aY, X, Y);
+          slot(hc, std::integral_constant<int, 0>{}, aX, aY, X, Y);
+        };
+        pair(std::integral_constant<int, 1>{});
+        pair(std::integral_constant<int, 0>{});
+        nib = (nibS | (nibC << 8)) & oknib;
+      }
+      const u32 w = nib | (from_lane_above(nib) << 4);
+      if (store_lane) {
+        u32 roff;
+        asm("s_mul_i32 %0, %1, %2" : "=s"(roff) : "s"(c), "s"(plane_pitch));
+        u32 so = st_off;
+        asm volatile("" : "+v"(so));
+        (splane + roff)[so] = (uint8_t)w;
+        (cplane + roff)[so] = (uint8_t)(w >> 8);
       }
     }
+  };
+
+  // source rows r0-2 .. rend+1, six per loop trip (the ring period); the next trip's rows are requested first
+  const int k0 = r0 - 2, kend = rend + 2;
+  u32 bn[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) bn[j] = load_row(k0 + j);
+#pragma nounroll
+  for (int k = k0; k < kend; k += 6) {
+    u32 bc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) bc[j] = bn[j];
+    if (k + 6 < kend)
+#pragma unroll
+      for (int j = 0; j < 6; ++j) bn[j] = load_row(k + 6 + j);
+    step(std::integral_constant<int, 0>{}, k + 0, bc[0]);
+    step(std::integral_constant<int, 1>{}, k + 1, bc[1]);
+    step(std::integral_constant<int, 2>{}, k + 2, bc[2]);
+    step(std::integral_constant<int, 3>{}, k + 3, bc[3]);
+    step(std::integral_constant<int, 4>{}, k + 4, bc[4]);
+    step(std::integral_constant<int, 5>{}, k + 5, bc[5]);
   }
 }
 
 hipError_t launch_front_o(const FrontParams &p, hipStream_t s)
 {
-  if (p.chunk_rows < 1 || p.bgr) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_front_o, dim3((p.total_items + 3) / 4), dim3(256), 0, s, p);
+  if (p.chunk_rows < 1 || p.bgr || (unsigned long long)p.H * p.in_pitch >= (1ull << 32)) return hipErrorInvalidValue;
+  const dim3 grid((p.total_items + 3) / 4), block(256);
+  if (p.l2gradient) hipLaunchKernelGGL(k_front_o<true>, grid, block, 0, s, p);
+  else hipLaunchKernelGGL(k_front_o<false>, grid, block, 0, s, p);
   return hipGetLastError();
 }
 

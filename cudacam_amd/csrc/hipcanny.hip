@@ -67,6 +67,7 @@ struct hc_ctx {
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
   int split = 1;        // front path as k_blur + k_nms (default) or the fused k_front
+  int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
   size_t bplane_fs = 0, bplane_frames = 0;
   int RD = 0;
@@ -337,6 +338,11 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     if (c->mode == HC_MODE_O) {
       // cv::Canny: plain thresholds on the L1 magnitude; long chunks (no LDS slab, 4-row warm-up)
       fp.a_lo[0] = (u32)c->low; fp.a_hi[0] = (u32)c->high;
+      fp.l2gradient = c->l2gradient;
+      if (c->l2gradient) {  // canny.cpp: thresholds capped at 32767 (hc_set_thresholds) and squared; the magnitude is dx^2 + dy^2
+        fp.a_lo[0] = (u32)c->low * (u32)c->low;
+        fp.a_hi[0] = (u32)c->high * (u32)c->high;
+      }
       const long units = (long)n_out * c->nstrips;
       const int per_strip = (int)std::max<long>(1, std::min<long>((12288 + units - 1) / units, (H + 15) / 16));
       fp.chunk_rows = (H + per_strip - 1) / per_strip;
@@ -532,6 +538,9 @@ int hc_set_option(hc_ctx *c, int option, int value)
     }
   } else if (option == HC_OPT_FRONT_SPLIT) {
     c->split = value != 0;
+  } else if (option == HC_OPT_L2_GRADIENT) {
+    if (c->mode != HC_MODE_O) return fail(HC_E_ARG, "HC_OPT_L2_GRADIENT applies to mode O contexts");
+    c->l2gradient = value != 0;
   } else if (option == HC_OPT_PIPELINE) {
     HIPCK(hipSetDevice(c->device));
     if (value && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;

@@ -29,7 +29,8 @@ typedef struct hc_ctx hc_ctx;
 enum { HC_STAGE_MONO = 0, HC_STAGE_GAUSSIAN = 1, HC_STAGE_GRADIENT = 2, HC_STAGE_NMS = 3, HC_STAGE_THRESH = 4, HC_STAGE_HYSTER = 5 };
 
 /* Parity modes.  R: bit-exact with the reference kernels (src/cvp/cannyEdgeD.cu).
- * O: bit-exact with OpenCV cv::Canny(img, low, high, 3, L2gradient=false) (no blur, replicate border). */
+ * O: bit-exact with OpenCV cv::Canny(img, low, high, 3, L2gradient) (no blur, replicate border; L2gradient
+ *    false unless HC_OPT_L2_GRADIENT is set). */
 enum { HC_MODE_R = 0, HC_MODE_O = 1 };
 
 enum {
@@ -130,8 +131,11 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  *
  * HC_OPT_FRONT_SPLIT (default 1, Mode R): 1 = the blur and the Sobel/NMS/threshold halves of the fused
  * path run as two kernels with a u8 blur plane between them (higher occupancy);
- * 0 = one fused kernel (no intermediate in HBM).  Results are identical. */
-enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4 };
+ * 0 = one fused kernel (no intermediate in HBM).  Results are identical.
+ *
+ * HC_OPT_L2_GRADIENT (default 0, Mode O contexts): cv::Canny's `L2gradient` argument: magnitude dx^2 + dy^2
+ * compared with the squared thresholds instead of |dx| + |dy|. */
+enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* Device self-test of the cross-lane / packed-math primitives the kernels rely on. 0 = ok. */

@@ -263,6 +263,20 @@ def test_mode_o_matches_cv_canny_restatement(oracle, name, make, low, high):
         _diff(ctx.process(img)[0], want, f"mode O {name}")
 
 
+@pytest.mark.parametrize("name,make,low,high", [m for m in MODE_O_IMAGES if m[0] in (
+    "natural_640x480", "noise_641x479", "noise_low_thresholds", "five", "flat255", "step_d", "serpentine", "natural_4k_strip")],
+    ids=lambda v: v if isinstance(v, str) else None)
+def test_mode_o_l2gradient(oracle, name, make, low, high):
+    """HC_OPT_L2_GRADIENT: cv::Canny(img, low, high, 3, true) -- squared magnitude against squared thresholds."""
+    img = make()
+    h, w = img.shape
+    want = oracle.canny_o(img, low, high, l2gradient=True)
+    with api.Context(w, h, 1, 1, api.MODE_O) as ctx:
+        ctx.set_thresholds(low, high)
+        ctx.set_option(api.OPT_L2_GRADIENT, 1)
+        _diff(ctx.process(img)[0], want, f"mode O L2 {name}")
+
+
 def test_pipelined_runs(oracle):
     """HC_OPT_PIPELINE: back-to-back device runs overlap (front of run i+1 / hysteresis of run i);
     every run's output must still be exactly the oracle's after hc_sync."""
