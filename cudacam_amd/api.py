@@ -50,6 +50,7 @@ ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
+    "hc_host_alloc", "hc_host_free",
 ]
 
 _lib = None

@@ -402,7 +402,22 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
 extern "C" {
 
 const char *hc_last_error(void) { return g_err.c_str(); }
-const char *hc_version(void) { return "hipcanny 0.2 (gfx950)"; }
+const char *hc_version(void) { return "hipcanny 0.3 (gfx950)"; }
+
+void *hc_host_alloc(size_t bytes)
+{
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    fail(HC_E_HIP, "hipHostMalloc failed");
+    return nullptr;
+  }
+  return p;
+}
+
+void hc_host_free(void *p)
+{
+  if (p) (void)hipHostFree(p);
+}
 
 hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch, int mode)
 {

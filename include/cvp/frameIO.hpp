@@ -1,0 +1,68 @@
+// include/cvp/frameIO.hpp -- the step either side of the hot path: frames from files into
+// the detector and edge maps back out, with the transfers overlapped.
+//
+// The reference gets its frames from cv::VideoCapture and shows the result through a GL pixel buffer
+// (src/imgui/imguiApp.cpp:427-431, 496-522; src/cvp/cannyEdgeH.cu:122-212); neither exists on a headless
+// MI355X.  This header is the headless counterpart:
+//   * cvp::io::readPNM / writePGM   binary PGM (P5, grey) and PPM (P6, RGB -> the BGR byte order cv::imread
+//                                   would deliver) -- formats that need no codec library;
+//   * cvp::io::FrameStreamer        a ring of `depth` slots, each with its own device context (own stream and
+//                                   device buffers) and page-locked staging: while slot k computes, slot k+1
+//                                   uploads and slot k-1 downloads.  Frames go in in order and come out in order.
+#pragma once
+#include "cvmat_min.hpp"
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+struct hc_ctx;
+
+namespace cvp
+{
+namespace io
+{
+  // Binary PNM (P5: 8-bit grey -> CV_8UC1, P6: 8-bit RGB -> CV_8UC3 in B,G,R order).  maxval must be 255.
+  bool readPNM(const std::string &path, cv::Mat &out);
+  // 8-bit single-channel image as binary PGM.
+  bool writePGM(const std::string &path, const cv::Mat &img);
+
+  class FrameStreamer
+  {
+  public:
+    // edges: `n` tight width x height u8 maps (0 / 255); firstIndex: running index of the first frame of the batch
+    using Sink = std::function<void(const std::uint8_t *edges, int n, long firstIndex)>;
+
+    FrameStreamer(int width, int height, int channels, int batch, int depth = 3, int device = 0);
+    ~FrameStreamer();
+    FrameStreamer(const FrameStreamer &) = delete;
+    FrameStreamer &operator=(const FrameStreamer &) = delete;
+
+    void setThresholds(int low, int high);
+    // page-locked staging of the next batch: `batch` frames of width*channels bytes per row, tight.  Fill it, then commit.
+    std::uint8_t *stage();
+    // queues upload + detector for the `n` frames written into stage(); if the ring is full, the oldest batch is
+    // completed first and handed to `sink`
+    void commit(int n, const Sink &sink);
+    // completes everything still in flight, oldest first
+    void flush(const Sink &sink);
+    long framesIn() const { return m_in; }
+
+  private:
+    struct Slot
+    {
+      hc_ctx *ctx = nullptr;
+      std::uint8_t *hostIn = nullptr, *hostOut = nullptr;
+      int n = 0;
+      long first = 0;
+      bool busy = false;
+    };
+    void complete(Slot &s, const Sink &sink);
+    int m_w, m_h, m_c, m_batch;
+    std::vector<Slot> m_slots;
+    int m_head = 0;// slot the next batch goes to (also the oldest one when the ring is full)
+    long m_in = 0;
+  };
+}// namespace io
+}// namespace cvp

@@ -138,6 +138,12 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
 enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
+/* Page-locked host memory for frame staging: hc_upload / hc_download on such buffers are true asynchronous DMA
+ * (the reference uploads from pageable cv::Mat memory with a blocking cudaMemcpy2D, cannyEdgeH.cu:136/144).
+ * Used by cvp::io::FrameStreamer (include/cvp/frameIO.hpp).  NULL on failure. */
+void *hc_host_alloc(size_t bytes);
+void hc_host_free(void *p);
+
 /* Device self-test of the cross-lane / packed-math primitives the kernels rely on. 0 = ok. */
 int hc_selftest(int device);
 

@@ -1,0 +1,82 @@
+// canny_files -- headless front end of the detector: binary PGM / PPM files in, <name>.edges.pgm out.
+//   canny_files [-o outdir] [--low L] [--high H] [--batch N] [--repeat R] file...
+// All files must have the same size and channel count.  Frames are streamed through cvp::io::FrameStreamer
+// (page-locked staging, upload / compute / download overlapped); prints the end-to-end rate, disk excluded
+// when --repeat re-streams the already loaded frames.
+#include "../include/cvp/frameIO.hpp"
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+int main(int argc, char **argv)
+{
+  std::string outdir = ".";
+  int low = 10, high = 40, batch = 16, repeat = 1;
+  std::vector<std::string> files;
+  for (int i = 1; i < argc; ++i) {
+    const std::string a = argv[i];
+    auto next = [&](int &v) { if (i + 1 < argc) v = std::atoi(argv[++i]); };
+    if (a == "-o" && i + 1 < argc) outdir = argv[++i];
+    else if (a == "--low") next(low);
+    else if (a == "--high") next(high);
+    else if (a == "--batch") next(batch);
+    else if (a == "--repeat") next(repeat);
+    else files.push_back(a);
+  }
+  if (files.empty()) {
+    std::fprintf(stderr, "usage: canny_files [-o outdir] [--low L] [--high H] [--batch N] [--repeat R] file.pgm|file.ppm ...\n");
+    return 2;
+  }
+  std::vector<cv::Mat> frames(files.size());
+  for (std::size_t i = 0; i < files.size(); ++i)
+    if (!cvp::io::readPNM(files[i], frames[i])) {
+      std::fprintf(stderr, "cannot read %s (binary P5/P6 with maxval 255 expected)\n", files[i].c_str());
+      return 1;
+    }
+  const int w = frames[0].cols, h = frames[0].rows, ch = frames[0].channels();
+  for (const cv::Mat &m : frames)
+    if (m.cols != w || m.rows != h || m.channels() != ch) {
+      std::fprintf(stderr, "all frames must share one size and channel count\n");
+      return 1;
+    }
+  if (batch < 1) batch = 1;
+  cvp::io::FrameStreamer streamer(w, h, ch, batch);
+  streamer.setThresholds(low, high);
+  const std::size_t frameBytes = static_cast<std::size_t>(w) * ch * h;
+  long written = 0;
+  int pass = 0;
+  auto sink = [&](const std::uint8_t *edges, int n, long first) {
+    if (pass != repeat - 1) return;// only the last pass is written out
+    for (int k = 0; k < n; ++k) {
+      const std::size_t idx = static_cast<std::size_t>((first + k) % static_cast<long>(files.size()));
+      std::string base = files[idx];
+      const std::size_t slash = base.find_last_of('/');
+      if (slash != std::string::npos) base = base.substr(slash + 1);
+      const std::size_t dot = base.find_last_of('.');
+      if (dot != std::string::npos) base = base.substr(0, dot);
+      cv::Mat img(h, w, CV_8UC1, const_cast<std::uint8_t *>(edges) + static_cast<std::size_t>(k) * w * h);
+      if (cvp::io::writePGM(outdir + "/" + base + ".edges.pgm", img)) ++written;
+    }
+  };
+  const auto t0 = std::chrono::steady_clock::now();
+  for (pass = 0; pass < repeat; ++pass) {
+    std::size_t i = 0;
+    while (i < frames.size()) {
+      std::uint8_t *dst = streamer.stage();
+      int n = 0;
+      for (; n < batch && i < frames.size(); ++n, ++i)
+        for (int r = 0; r < h; ++r) std::memcpy(dst + n * frameBytes + static_cast<std::size_t>(r) * w * ch, frames[i].ptr(r), static_cast<std::size_t>(w) * ch);
+      streamer.commit(n, sink);
+    }
+    if (pass == repeat - 1) streamer.flush(sink);
+    else streamer.flush(cvp::io::FrameStreamer::Sink());
+  }
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("{\"frames\": %ld, \"width\": %d, \"height\": %d, \"channels\": %d, \"batch\": %d, \"seconds\": %.6f, \"frames_per_s\": %.1f, \"written\": %ld}\n",
+              streamer.framesIn(), w, h, ch, batch, dt, streamer.framesIn() / dt, written);
+  return 0;
+}
