@@ -1377,6 +1377,33 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       if (threadIdx.x == 0) tf_cur[bt] = 0;
       return;
     }
+    // A neighbour's boundary row changed somewhere -- but does a new bit reach a candidate of this tile?  Only
+    // then can anything change here (the tile is at its own fixpoint).  Checked on the two boundary rows alone
+    // (4 row loads) before the 2 x TR rows per wave are fetched: most tiles leave here in launches >= 1.
+    {
+      u32 *S0 = p.sbits + (size_t)frame * H * RD;
+      const u32 *C0 = p.cbits + (size_t)frame * H * RD;
+      bool hit = false;
+      auto reaches = [&](int halo_row, int my_row) {
+        const RowBits<NW> hv = row_load<NW>(S0 + (size_t)halo_row * RD, lane, RD);
+        const RowBits<NW> sv = row_load<NW>(S0 + (size_t)my_row * RD, lane, RD), cv = row_load<NW>(C0 + (size_t)my_row * RD, lane, RD);
+        const RowBits<NW> d = row_dilate<NW>(hv);
+        bool h = false;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) h = h || ((cv.w[j] & d.w[j] & ~sv.w[j]) != 0);
+        return __ballot(h) != 0;
+      };
+      if (top && wib == 0) hit = reaches(b0 - 1, b0);
+      if (bot && wib == WAVES - 1) hit = reaches(b0 + nb, b0 + nb - 1) || hit;
+      if (threadIdx.x == 0) bchg[20] = 0;
+      __syncthreads();
+      if (hit && lane == 0) atomicOr(&bchg[20], 1u);
+      __syncthreads();
+      if (__builtin_amdgcn_readfirstlane(bchg[20]) == 0) {
+        if (threadIdx.x == 0) tf_cur[bt] = 0;
+        return;
+      }
+    }
   }
   // this wave's rows inside the workgroup tile
   const int w0 = min(wib * TR, nb), n = min((wib + 1) * TR, nb) - w0;
