@@ -16,5 +16,6 @@ for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_C
   timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OUT/pmc_$n" -- $BENCH > /dev/null 2> "$OUT/pmc_$n.log"
   python3 "$R/tools/pmc_summary.py" "$OUT/pmc_$n" >> "$OUT/pmc_summary.txt"
 done
+python3 "$R/tools/pmc_traffic.py" "$OUT/pmc_summary.txt" "$OUT/bench_under_rocprof_stats.json" > "$OUT/pmc_traffic.json"
 rm -rf "$OUT"/stats "$OUT"/pmc_*/ "$OUT"/*.log
 ls -la "$OUT"
