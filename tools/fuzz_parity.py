@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Randomised parity run on the GPU box: random sizes, contents, thresholds, options and batch sizes, product vs oracle.
+Usage: tools/fuzz_parity.py [cases] [seed]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from cudacam_amd import api, synth
+from oracle import oracle as O
+
+O.build()
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
+bad = 0
+t0 = time.time()
+for i in range(cases):
+    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), rng.integers(240, 260), rng.integers(490, 510), rng.integers(600, 2200)]))
+    h = int(rng.choice([rng.integers(1, 12), rng.integers(12, 120), rng.integers(120, 400)]))
+    kind = rng.choice(["noise", "natural", "flat", "steps", "sparse", "saturated"])
+    seed = int(rng.integers(1, 1 << 30))
+    if kind == "noise": img = synth.noise(w, h, seed)
+    elif kind == "natural": img = synth.natural(w, h, seed)
+    elif kind == "flat": img = synth.flat(w, h, int(rng.integers(0, 256)))
+    elif kind == "steps": img = synth.steps(w, h, int(rng.integers(1, 256)), str(rng.choice(["vertical", "horizontal", "diagonal"])))
+    elif kind == "sparse":
+        img = np.zeros((h, w), np.uint8); k = max(1, w * h // 50)
+        img[rng.integers(0, h, k), rng.integers(0, w, k)] = rng.integers(1, 256, k)
+    else:
+        img = (rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)
+    mode = "R" if rng.random() < 0.75 else "O"
+    low, high = sorted(int(x) for x in rng.integers(0, 256 if mode == "R" else 600, 2))
+    nb = int(rng.integers(1, 4))
+    frames = np.stack([np.roll(img, 3 * k, axis=1) for k in range(nb)])
+    opts = {}
+    if mode == "R":
+        opts["sat"] = int(rng.integers(0, 2)); opts["split"] = int(rng.integers(0, 2)); opts["chunk"] = int(rng.choice([0, 2, 9, 24, 50, 400]))
+        want = np.stack([O.canny_r(f, low, high, saturate=bool(opts["sat"])) for f in frames])
+    else:
+        opts["l2"] = int(rng.integers(0, 2))
+        want = np.stack([O.canny_o(f, low, high, l2gradient=bool(opts["l2"])) for f in frames])
+    ch = 1
+    if mode == "R" and rng.random() < 0.3:   # interleaved 3-channel input: grey conversion (fused or fallback) or per-channel maps
+        ch = 3
+        frames = np.stack([np.stack([np.roll(f, 5 * c, axis=0) ^ np.uint8(17 * c) for c in range(3)], axis=-1) for f in frames])
+        opts["pc"] = int(rng.integers(0, 2))
+        if opts["pc"]:
+            want = np.stack([O.canny_r(np.ascontiguousarray(f[:, :, c]), low, high, saturate=bool(opts["sat"])) for f in frames for c in range(3)])
+        else:
+            want = np.stack([O.canny_r(f, low, high, saturate=bool(opts["sat"])) for f in frames])
+    with api.Context(w, h, ch, nb, api.MODE_R if mode == "R" else api.MODE_O) as ctx:
+        if ch == 3 and opts["pc"]:
+            ctx.set_option(api.OPT_PER_CHANNEL, 1)
+        ctx.set_thresholds(low, high)
+        if mode == "R":
+            ctx.set_option(api.OPT_NMS_SATURATE, opts["sat"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)
+        else:
+            ctx.set_option(api.OPT_L2_GRADIENT, opts["l2"])
+        n_in = ctx.upload(frames)
+        ctx.run(api.CannyStage.HYSTER, n_in)
+        got = ctx.download(len(want))
+    if not np.array_equal(got, want):
+        bad += 1
+        d = np.argwhere(got != want)
+        print(f"MISMATCH case {i}: {w}x{h} {kind} seed {seed} mode {mode} thr {low}/{high} nb {nb} {opts}: {len(d)} px, first {d[0].tolist()}", flush=True)
+print(f"fuzz: {cases} cases, {bad} mismatches, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
