@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity run on the GPU box: random sizes, contents, thresholds, options and batch sizes, product vs oracle.
-Usage: tools/fuzz_parity.py [cases] [seed]"""
+Usage: tests/fuzz_parity.py [cases] [seed]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 from cudacam_amd import api, synth
 from oracle import oracle as O
 

@@ -1,4 +1,4 @@
-"""Randomised parity sweep (tools/fuzz_parity.py): sizes 1..2200 x 1..400, six kinds of content, both modes, every
+"""Randomised parity sweep (tests/fuzz_parity.py): sizes 1..2200 x 1..400, six kinds of content, both modes, every
 option (saturating NMS, fused / split front path, run lengths, L2 gradient, BGR and per-channel input), batches of
 1..3 frames -- product vs oracle, bit for bit.  The longer runs (thousands of cases) are done by hand with the tool."""
 import os
@@ -13,6 +13,6 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1, 2])
 def test_random_cases_match_oracle(oracle, seed):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "150", str(seed)], capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "150", str(seed)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "0 mismatches" in out.stdout
