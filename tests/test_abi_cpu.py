@@ -57,6 +57,12 @@ def test_product_does_not_touch_oracle():
     for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
         for f in files:
             assert "canny_oracle" not in open(os.path.join(dirpath, f), errors="ignore").read()
+    # tools/ (benchmark helpers, profiling scripts, the file front end) stay clear of it too
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "tools")):
+        for f in files:
+            if f.endswith((".py", ".sh", ".cpp", ".hip")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "canny_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
 
 
 def test_stage_names():
