@@ -51,9 +51,10 @@ struct HystParams {
   int RD, H, nframes;
   int tile_rows;   // rows per wave
   int waves;       // waves per workgroup; a workgroup tile is waves * tile_rows rows
-  int nrtiles;     // workgroup tiles per frame = ceil(H / (waves * tile_rows))
+  int nrtiles;     // row tiles per frame = ceil(H / (waves * tile_rows))
+  int npanels;     // column panels per row tile = RD / 64 (a panel = 64 dwords = 2048 columns)
   u32 *flags;      // flags[k] != 0: launch k changed a tile-boundary row (another launch is needed)
-  uint8_t *tflags; // [2][nframes][nrtiles]: bit0 first row changed, bit1 last row changed (per launch parity)
+  uint8_t *tflags; // [2][nframes][nrtiles * npanels]: 1 first row, 2 last row, 4 first column, 8 last column changed (per launch parity)
   int iter;        // index of this launch
   u32 *stats;      // optional diagnostics (3 words per launch) or null
   // fused expand: every launch also writes the 0/255 u8 rows it owns (launch 0: all rows of the tile,

@@ -1341,8 +1341,7 @@ static inline HystGeom hyst_geom(int RD)
     }
     return { 1, 32, 8 };  // 256 rows per workgroup
   }
-  if (RD <= 128) return { 2, 32, 8 };   // 256 rows
-  return { 4, 16, 8 };                  // 128 rows
+  return { 1, 32, 8 };  // wider frames: several column panels of the same tile shape
 }
 void hyst_tile_geometry(int RD, int *tile_rows, int *waves)
 {
@@ -1363,24 +1362,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   __shared__ u32 edge[(2 * WAVES + 2) * ROWW];  // per wave: first and last row of S; then the two halo rows
   __shared__ u32 bchg[24];
   const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int bt = blockIdx.x % p.nrtiles, frame = blockIdx.x / p.nrtiles;
+  // tiles are 2-D: row tile bt x column panel pn (a panel = ROWW dwords = 2048 columns; frames up to 2048
+  // columns have one panel).  A wave always holds one dword per lane and row, whatever the frame width.
+  const int NP = p.npanels, ntile = p.nrtiles * NP;
+  const int tile = blockIdx.x % ntile, frame = blockIdx.x / ntile;
+  const int bt = tile / NP, pn = tile % NP;
   const int H = p.H, RD = p.RD;
+  const int pcol = pn * ROWW;                          // first dword of this panel in a plane row
   const int b0 = bt * BR, nb = min(H, b0 + BR) - b0;  // rows of this workgroup tile
-  uint8_t *tf_prev = p.tflags + (size_t)((p.iter + 1) & 1) * p.nframes * p.nrtiles + (size_t)frame * p.nrtiles;
-  uint8_t *tf_cur = p.tflags + (size_t)(p.iter & 1) * p.nframes * p.nrtiles + (size_t)frame * p.nrtiles;
-  bool top = false, bot = false;
+  uint8_t *tf_prev = p.tflags + (size_t)((p.iter + 1) & 1) * p.nframes * ntile + (size_t)frame * ntile;
+  uint8_t *tf_cur = p.tflags + (size_t)(p.iter & 1) * p.nframes * ntile + (size_t)frame * ntile;
+  // tile flags: 1 first row changed, 2 last row changed, 4 first column changed, 8 last column changed
+  bool top = false, bot = false, side = false;
   if (p.iter > 0) {
-    // work only if a neighbouring tile changed the row this tile looks at
-    top = bt > 0 && (__builtin_amdgcn_readfirstlane(tf_prev[bt - 1]) & 2);
-    bot = bt + 1 < p.nrtiles && (__builtin_amdgcn_readfirstlane(tf_prev[bt + 1]) & 1);
-    if (!top && !bot) {  // uniform for the workgroup
-      if (threadIdx.x == 0) tf_cur[bt] = 0;
+    // work only if a neighbouring tile changed the row / column / corner this tile looks at
+    auto flag = [&](int t, int q) -> int { return (t >= 0 && t < p.nrtiles && q >= 0 && q < NP) ? __builtin_amdgcn_readfirstlane(tf_prev[t * NP + q]) : 0; };
+    top = ((flag(bt - 1, pn) | flag(bt - 1, pn - 1) | flag(bt - 1, pn + 1)) & 2) != 0;
+    bot = ((flag(bt + 1, pn) | flag(bt + 1, pn - 1) | flag(bt + 1, pn + 1)) & 1) != 0;
+    side = (flag(bt, pn - 1) & 8) != 0 || (flag(bt, pn + 1) & 4) != 0;
+    if (!top && !bot && !side) {  // uniform for the workgroup
+      if (threadIdx.x == 0) tf_cur[tile] = 0;
       return;
     }
     // A neighbour's boundary row changed somewhere -- but does a new bit reach a candidate of this tile?  Only
     // then can anything change here (the tile is at its own fixpoint).  Checked on the two boundary rows alone
     // (4 row loads) before the 2 x TR rows per wave are fetched: most tiles leave here in launches >= 1.
-    {
+    if (!side && NP == 1) {
       u32 *S0 = p.sbits + (size_t)frame * H * RD;
       const u32 *C0 = p.cbits + (size_t)frame * H * RD;
       bool hit = false;
@@ -1400,7 +1407,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       if (hit && lane == 0) atomicOr(&bchg[20], 1u);
       __syncthreads();
       if (__builtin_amdgcn_readfirstlane(bchg[20]) == 0) {
-        if (threadIdx.x == 0) tf_cur[bt] = 0;
+        if (threadIdx.x == 0) tf_cur[tile] = 0;
         return;
       }
     }
@@ -1410,7 +1417,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   const bool owns_last = n > 0 && w0 + n == nb;
   const u64 all_rows = n >= 64 ? ~0ull : ((1ull << n) - 1);
   u64 dirty;  // bit r = row b0 + w0 + r needs (re)evaluation
-  if (p.iter > 0) dirty = ((top && w0 == 0 && n > 0) ? 1ull : 0ull) | ((bot && owns_last) ? (1ull << (n - 1)) : 0ull);
+  if (p.iter > 0) dirty = side ? all_rows : (((top && w0 == 0 && n > 0) ? 1ull : 0ull) | ((bot && owns_last) ? (1ull << (n - 1)) : 0ull));
   else dirty = all_rows;
   dirty = uniform64(dirty);
   u64 unfilled = p.first_pass ? all_rows : 0ull;  // rows not yet closed under the in-row fill
@@ -1426,8 +1433,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   for (int i = 0; i < TR; ++i) {
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const bool ok = i < n && lane * NW + j < RD;
-      const size_t off = (size_t)(b0 + w0 + i) * RD + lane * NW + j;
+      const bool ok = i < n && pcol + lane * NW + j < RD;
+      const size_t off = (size_t)(b0 + w0 + i) * RD + pcol + lane * NW + j;
       cr[j][i] = ok ? C[off] : 0u;
       sr[j][i] = ok ? S[off] : 0u;
     }
@@ -1448,7 +1455,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 #pragma unroll
     for (int j = 0; j < NW; ++j) v.w[j] = 0;
     if (wib == 0) {
-      if (gr >= 0) v = row_load<NW>(S + (size_t)gr * RD, lane, RD);
+      if (gr >= 0) v = row_load<NW>(S + (size_t)gr * RD + pcol, lane, RD - pcol);
 #pragma unroll
       for (int j = 0; j < NW; ++j) halo_top[lane * NW + j] = v.w[j];
     }
@@ -1457,10 +1464,22 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       RowBits<NW> vb;
 #pragma unroll
       for (int j = 0; j < NW; ++j) vb.w[j] = 0;
-      if (gb < H) vb = row_load<NW>(S + (size_t)gb * RD, lane, RD);
+      if (gb < H) vb = row_load<NW>(S + (size_t)gb * RD + pcol, lane, RD - pcol);
 #pragma unroll
       for (int j = 0; j < NW; ++j) halo_bot[lane * NW + j] = vb.w[j];
     }
+  }
+  // Column halos (frames wider than one panel): the strong bits just left / right of the panel, for this wave's
+  // rows and the row above / below them -- bit k of the mask = row w0 - 1 + k.  Like the row halos they belong to
+  // other workgroups and are as of the start of this launch.
+  u64 lmask = 0, rmask = 0;
+  if (NP > 1 && n > 0) {
+    const int hr = b0 + w0 - 1 + lane;  // lanes 0 .. n+1 fetch one row each
+    const bool rok = lane < n + 2 && hr >= 0 && hr < H;
+    const u32 lv = (rok && pn > 0) ? S[(size_t)hr * RD + pcol - 1] : 0u;
+    const u32 rv = (rok && pn + 1 < NP) ? S[(size_t)hr * RD + pcol + ROWW] : 0u;
+    lmask = uniform64(__ballot((lv >> 31) != 0));
+    rmask = uniform64(__ballot((rv & 1u) != 0));
   }
   if (threadIdx.x < 24) bchg[threadIdx.x] = 0;
   __syncthreads();
@@ -1471,6 +1490,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   // row's new strong bits reach candidates of the row above.  Work is proportional to the rows that
   // change.  Waves exchange their boundary rows through LDS between rounds.
   u64 changed = 0;
+  u32 colchg = 0;  // bit 0: first column of the panel changed, bit 1: last column
   for (int round = 0; round < (p.debug_skip ? 0 : 4096); ++round) {
     u64 round_changed = 0;
     while (dirty) {
@@ -1487,7 +1507,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       RowBits<NW> nbr;
 #pragma unroll
       for (int j = 0; j < NW; ++j) nbr.w[j] = up.w[j] | dn.w[j];
-      const RowBits<NW> d = row_dilate<NW>(nbr);
+      RowBits<NW> d = row_dilate<NW>(nbr);
+      if (NP > 1) {  // a strong pixel in the column next to the panel, rows r-1 .. r+1, touches my first / last column
+        if (((lmask >> r) & 7ull) != 0 && lane == 0) d.w[0] |= 1u;
+        if (((rmask >> r) & 7ull) != 0 && lane == 63) d.w[NW - 1] |= 0x80000000u;
+      }
       RowBits<NW> seed;
       bool grew = false, hs = false, hc = false;
 #pragma unroll
@@ -1508,6 +1532,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 #pragma unroll
       for (int j = 0; j < NW; ++j) ch = ch || (f.w[j] != s.w[j]);
       if (__ballot(ch) == 0) continue;
+      if (NP > 1) {  // did the panel's first / last column change? (lane 0 bit 0, lane 63 bit 31)
+        const u32 x0 = f.w[0] ^ s.w[0], x1 = f.w[NW - 1] ^ s.w[NW - 1];
+        colchg |= (u32)(__builtin_amdgcn_readlane((int)x0, 0) & 1) | (((u32)__builtin_amdgcn_readlane((int)x1, 63) >> 31) << 1);
+      }
 #pragma unroll
       for (int j = 0; j < NW; ++j) sr[j][r] = f.w[j];
       if (r == 0) publish(my_first, 0);
@@ -1536,7 +1564,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
     const int r = __builtin_ctzll(m);
 #pragma unroll
     for (int j = 0; j < NW; ++j) {
-      const int dd = lane * NW + j;
+      const int dd = pcol + lane * NW + j;
       if (dd < RD) S[(size_t)(b0 + w0 + r) * RD + dd] = sr[j][r];
     }
   }
@@ -1551,9 +1579,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       u32 rowv[NW];
 #pragma unroll
       for (int j = 0; j < NW; ++j) rowv[j] = sr[j][r];
-      for (int pass = 0; pass * 1024 < p.W; ++pass) {
-        // this lane writes px [1024*pass + 16*lane, +16): half-word 64*pass + lane of the row
-        const int D = 32 * pass + (lane >> 1);  // dword holding it
+      for (int pass = 0; pass * 1024 < ROWW * 32 && pcol * 32 + pass * 1024 < p.W; ++pass) {
+        // this lane writes px [32*pcol + 1024*pass + 16*lane, +16): half-word 64*pass + lane of the panel row
+        const int D = 32 * pass + (lane >> 1);  // dword (of the panel) holding it
         u32 x = 0;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
@@ -1561,7 +1589,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
           x = (D % NW) == j ? t : x;
         }
         const u32 b = (x >> (16 * (lane & 1))) & 0xFFFFu;
-        const int c0 = pass * 1024 + lane * 16;
+        const int c0 = pcol * 32 + pass * 1024 + lane * 16;
         if (c0 >= p.W) continue;
         u32 v[4];
 #pragma unroll
@@ -1580,11 +1608,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   }
   const bool first_changed = n > 0 && w0 == 0 && (changed & 1ull);
   const bool last_changed = owns_last && ((changed >> (n - 1)) & 1ull);
-  if (lane == 0 && (first_changed || last_changed)) atomicOr(&bchg[16], (first_changed ? 1u : 0u) | (last_changed ? 2u : 0u));
+  if (lane == 0 && (first_changed || last_changed || colchg)) atomicOr(&bchg[16], (first_changed ? 1u : 0u) | (last_changed ? 2u : 0u) | (colchg << 2));
   __syncthreads();
   if (threadIdx.x == 0) {
     const u32 vis = bchg[16];
-    tf_cur[bt] = (uint8_t)vis;
+    tf_cur[tile] = (uint8_t)vis;
     if (vis) atomicOr(&p.flags[p.iter], 1u);
   }
   if (lane == 0 && p.stats && n > 0) {  // diagnostics (opt-in): changed rows summed / max over wave tiles, active wave tiles
@@ -1599,13 +1627,13 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
 {
   const HystGeom g = hyst_geom(p.RD);
   if (p.RD > 256 || p.tile_rows != g.tr || p.waves != g.waves) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)(p.nframes * p.nrtiles)), block(64 * g.waves);
+  if (p.npanels != (p.RD + 63) / 64 || p.RD % 64) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)(p.nframes * p.nrtiles * p.npanels)), block(64 * g.waves);
   if (g.nw == 1 && g.tr == 32 && g.waves == 8) hipLaunchKernelGGL((k_hyst<1, 32, 8>), grid, block, 0, s, p);
   else if (g.nw == 1 && g.tr == 32 && g.waves == 4) hipLaunchKernelGGL((k_hyst<1, 32, 4>), grid, block, 0, s, p);
   else if (g.nw == 1 && g.tr == 16 && g.waves == 8) hipLaunchKernelGGL((k_hyst<1, 16, 8>), grid, block, 0, s, p);
   else if (g.nw == 1 && g.tr == 32 && g.waves == 16) hipLaunchKernelGGL((k_hyst<1, 32, 16>), grid, block, 0, s, p);
-  else if (g.nw == 2) hipLaunchKernelGGL((k_hyst<2, 32, 8>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((k_hyst<4, 16, 8>), grid, block, 0, s, p);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 

@@ -117,7 +117,7 @@ int alloc_slot(hc_ctx *c, Slot &s)
   // row padding beyond the strips' bytes is never written by the kernels and must read as 0
   HIPCK(hipMemset(s.d_sbits, 0, plane_bytes));
   HIPCK(hipMemset(s.d_cbits, 0, plane_bytes));
-  HIPCK(hipMalloc((void **)&s.d_tflags, (size_t)2 * out_frames * ((c->H + 7) / 8 + 1)));
+  HIPCK(hipMalloc((void **)&s.d_tflags, (size_t)2 * out_frames * ((size_t)(c->H + 7) / 8 + 1) * ((c->RD + 63) / 64)));
   HIPCK(hipMalloc((void **)&s.d_flags, sizeof(u32) * FLAG_WORDS));
   HIPCK(hipHostMalloc((void **)&s.h_flags, sizeof(u32) * FLAG_WORDS, hipHostMallocDefault));
   HIPCK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
@@ -231,10 +231,11 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
   hyst_tile_geometry(c->RD, &hp.tile_rows, &hp.waves);
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
+  hp.npanels = (c->RD + 63) / 64;
   (void)small_tiles;
   // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
   // tall frame (later launches exit at once after convergence; beyond the queue, hc_sync continues from the host)
-  const int K = c->hyst_launches_set ? c->hyst_launches : std::min(MAX_HYST_LAUNCHES, std::max(c->hyst_launches, hp.nrtiles + 1));
+  const int K = c->hyst_launches_set ? c->hyst_launches : std::min(MAX_HYST_LAUNCHES, std::max(c->hyst_launches, hp.nrtiles + hp.npanels));
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
   hp.debug_skip = getenv("HC_DEBUG_SKIP_HYST") ? 1 : 0;

@@ -198,8 +198,21 @@ def test_hysteresis_device_adversarial(oracle):
         "random_dense": synth.thresh_map_random(777, 555, 3, 0.45, 0.002),
         "random_sparse": synth.thresh_map_random(1920, 1080, 4, 0.30, 0.0005),
         "all_candidates_one_seed": np.full((130, 520), 128, np.uint8),
+        # frames wider than one 2048-column panel: the path crosses the panel seams (and the row tiles) again and again
+        "serpentine_4500x300": synth.thresh_map_serpentine(4500, 300),
+        "serpentine_8184x70": synth.thresh_map_serpentine(8184, 70),
+        "random_wide": synth.thresh_map_random(6100, 300, 9, 0.45, 0.001),
+        "all_candidates_one_seed_wide": np.full((300, 5000), 128, np.uint8),
+        "diagonal_across_seams": np.zeros((600, 4200), np.uint8),
     }
     cases["all_candidates_one_seed"][129, 519] = 255
+    cases["all_candidates_one_seed_wide"][299, 4999] = 255
+    dg = cases["diagonal_across_seams"]   # a 1-px anti-diagonal and a diagonal through the tile corners at (256, 2048)
+    for i in range(600):
+        dg[i, 2048 - 256 + i] = 128
+        dg[i, 2048 + 255 - i] = 128
+    dg[0, 2048 - 256] = 255
+    dg[599, 2048 + 255 - 599] = 255
     for name, t in cases.items():
         h, w = t.shape
         want = oracle.hysteresis(t)
