@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 12345)
 bad = 0
 t0 = time.time()
 for i in range(cases):
-    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), rng.integers(240, 260), rng.integers(490, 510), rng.integers(600, 2200)]))
+    w = int(rng.choice([rng.integers(1, 40), rng.integers(40, 600), rng.integers(240, 260), rng.integers(490, 510), rng.integers(600, 2200), rng.integers(2040, 8185)]))
     h = int(rng.choice([rng.integers(1, 12), rng.integers(12, 120), rng.integers(120, 400)]))
     kind = rng.choice(["noise", "natural", "flat", "steps", "sparse", "saturated"])
     seed = int(rng.integers(1, 1 << 30))
