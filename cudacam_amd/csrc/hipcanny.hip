@@ -146,11 +146,13 @@ int ensure_blur_plane(hc_ctx *c)
   return HC_OK;
 }
 
-// rows per work item: enough items for a few rounds of the whole chip (8192 resident waves), runs as long as possible
+// rows per work item: about 16 rounds of the whole chip (8192 resident waves) when the batch allows it -- the tail of a
+// launch is one work item long, measured optimum 68-135 rows at 1024 frames -- but never runs shorter than 64 rows
+// (each run repeats a 4-row warm-up)
 int pick_run_rows(long units, int H, int want_rows)
 {
   if (want_rows > 0) return std::min(std::max(want_rows, 2), H);
-  const long nch = std::min<long>(std::max<long>((4 * 8192 + units - 1) / units, 1), std::max(1, H / 16));
+  const long nch = std::min<long>(std::max<long>((16 * 8192 + units - 1) / units, 1), std::max(1, H / 64));
   return (int)((H + nch - 1) / nch);
 }
 
