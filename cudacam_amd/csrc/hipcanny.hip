@@ -231,10 +231,9 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   HystParams hp{};
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags; hp.tflags = s.d_tflags;
   // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
-  hyst_tile_geometry(c->RD, &hp.tile_rows, &hp.waves);
+  hyst_tile_geometry(c->RD, small_tiles, &hp.tile_rows, &hp.waves);
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
   hp.npanels = (c->RD + 63) / 64;
-  (void)small_tiles;
   // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
   // tall frame (later launches exit at once after convergence; beyond the queue, hc_sync continues from the host)
   const int K = c->hyst_launches_set ? c->hyst_launches : std::min(MAX_HYST_LAUNCHES, std::max(c->hyst_launches, hp.nrtiles + hp.npanels));
