@@ -809,6 +809,7 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
   const u32 pm0 = __builtin_amdgcn_perm(0u, cmask, 0x01010000u), pm1 = __builtin_amdgcn_perm(0u, cmask, 0x03030202u);
   const u32 oknib1 = (lane >= 1 && lane <= 62) ? ((cmask & 1u) | ((cmask >> 7) & 2u) | ((cmask >> 14) & 4u) | ((cmask >> 21) & 8u)) : 0u;
   const u32 oknib = oknib1 | (oknib1 << 8);
+  const u32 bm0 = pm0, bm1 = pm1;  // packed-i16 column masks of the two pixel pairs
   // own columns from this strip's segment; the halo lanes read the dword the neighbouring strip owns
   // (lane 0 <- strip-1 lane 62, lane 63 <- strip+1 lane 1); lanes without an image column read nothing (0)
   const uint8_t *bframe = p.blur + (size_t)frame * p.blur_frame_stride;  // wave-uniform
@@ -859,12 +860,21 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
     dk[1] = R(I(p3) - I(p1));
     sk[1] = pk_mad2(B, p1 + p3);
     const int i = k - 1;
-    const u32 rowm = (i >= 0 && i < H) ? 0xFFFFFFFFu : 0u;
+    const bool rowbad = i < 0 || i >= H;  // the Sobel rows just above / below the image are 0 (zero padding of every stage)
+    u32 Xv[2], Yv[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const u32 pm = (h == 0 ? pm0 : pm1) & rowm;
-      const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;
-      const u32 Y = R(I(sr[rn][h]) - I(sk[h])) & pm;
+      // column masks: only the first and the last strips have columns outside the image (bmask is all ones elsewhere)
+      Xv[h] = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & (h == 0 ? bm0 : bm1);
+      Yv[h] = R(I(sr[rn][h]) - I(sk[h])) & (h == 0 ? bm0 : bm1);
+    }
+    if (rowbad) {  // wave-uniform, two rows per frame
+      asm volatile("" ::: "memory");  // keeps this one branch: as selects it would cost every row extra VALU ops
+      Xv[0] = Xv[1] = Yv[0] = Yv[1] = 0;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32 X = Xv[h], Y = Yv[h];
       Xr[rn][h] = X;
       Yr[rn][h] = Y;
       Sr[sN][1 + 2 * h] = (u32)mad16<0, 0>(X, X, mul16<0, 0>(Y, Y));
@@ -1068,12 +1078,20 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
     dk[1] = R(I(p3) - I(p1));
     sk[1] = pk_mad2(B, p1 + p3);
     const int i = k - 1;  // gradient row from source rows k-2 (ring rn), k-1 (ring rp), k (new)
-    const u32 rowm = (i >= 0 && i < H) ? 0xFFFFFFFFu : 0u;  // magnitude outside the image is 0
+    const bool rowbad = i < 0 || i >= H;  // magnitude outside the image is 0
+    u32 Xv[2], Yv[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const u32 pm = (h == 0 ? pm0 : pm1) & rowm;
-      const u32 X = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & pm;  // dx = right - left, smoothed 1-2-1 down the rows
-      const u32 Y = R(I(sk[h]) - I(sr[rn][h])) & pm;                       // dy = bottom - top
+      Xv[h] = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & (h == 0 ? pm0 : pm1);  // dx = right - left, smoothed 1-2-1 down the rows
+      Yv[h] = R(I(sk[h]) - I(sr[rn][h])) & (h == 0 ? pm0 : pm1);                       // dy = bottom - top
+    }
+    if (rowbad) {  // wave-uniform, two rows per frame
+      asm volatile("" ::: "memory");  // keeps this one branch instead of per-row selects
+      Xv[0] = Xv[1] = Yv[0] = Yv[1] = 0;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const u32 X = Xv[h], Y = Yv[h];
       Xr[rn][h] = X;
       Yr[rn][h] = Y;
       if (L2) {
