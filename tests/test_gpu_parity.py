@@ -329,3 +329,41 @@ def test_python_mirror_of_reference_operator(oracle):
     pipe.setHighThreshold(5)      # max(high, low) -> 40
     assert pipe.getHighThreshold() == 40
     assert api.TimerManager.Get().getAverageTime(api.CANNY_STAGES[api.CannyStage.HYSTER]) >= 0.0
+
+
+def test_context_reuse_sequences(oracle):
+    """One context, many different calls in a row: batch sizes going up and down, thresholds, options and stage taps
+    changing between runs, pipelined and plain -- no state may leak from one run into the next."""
+    import torch
+    w, h, nb = 700, 300, 4
+    frames = np.stack([synth.natural(w, h, 60 + f) for f in range(nb)])
+    noise = np.stack([synth.noise(w, h, 80 + f) for f in range(nb)])
+    with api.Context(w, h, 1, nb) as ctx:
+        for pipelined in (0, 1, 0):
+            ctx.set_option(api.OPT_PIPELINE, pipelined)
+            for (src, n, low, high, split, sat) in [(frames, 4, 10, 40, 1, 0), (noise, 1, 30, 90, 0, 1), (frames, 2, 0, 255, 1, 1),
+                                                     (noise, 4, 5, 6, 1, 0), (frames, 3, 10, 40, 0, 0)]:
+                ctx.set_thresholds(low, high)
+                ctx.set_option(api.OPT_FRONT_SPLIT, split)
+                ctx.set_option(api.OPT_NMS_SATURATE, sat)
+                got = ctx.process(src[:n])
+                for f in range(n):
+                    _diff(got[f], oracle.canny_r(src[f], low, high, saturate=bool(sat)), f"pipelined {pipelined} n {n} thr {low}/{high} split {split} sat {sat} frame {f}")
+            ctx.set_option(api.OPT_NMS_SATURATE, 0)
+            ctx.set_thresholds(10, 40)
+            st = oracle.canny_r(frames[1], 10, 40, stages=True)
+            got = ctx.process(frames[1:2], api.CannyStage.GAUSSIAN)
+            _diff(got[0], st["blur"], "gaussian tap after fused runs")
+        # device path, pipelined, batches of different size back to back without a sync in between
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        ctx.set_option(api.OPT_FRONT_SPLIT, 1)
+        d_in = torch.from_numpy(np.concatenate([frames, noise])).cuda()
+        d_out = torch.zeros_like(d_in)
+        plan = [(0, 4), (4, 2), (6, 1), (7, 1), (1, 3)]
+        for (f0, n) in plan:
+            ctx.run_device(d_in[f0].data_ptr(), w, w * h, d_out[f0].data_ptr(), w, w * h, n)
+        ctx.sync()
+        allf = np.concatenate([frames, noise])
+        got = d_out.cpu().numpy()
+        for f in range(8):
+            _diff(got[f], oracle.canny_r(allf[f], 10, 40), f"pipelined device runs, frame {f}")
