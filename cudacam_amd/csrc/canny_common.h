@@ -42,6 +42,9 @@ struct FrontParams {
   uint8_t *blur;             // [frame][strip][H][256]: one aligned 256-byte row per wave-row (bytes 4..251 = the strip's columns)
   size_t blur_frame_stride;  // >= nstrips * H * 256
   int nchunks_b, run_rows_b, total_items_b;
+  // k_nms: when set, the strong pixels are also written as 255 (others 0) into this u8 map -- the provisional edge
+  // map the hysteresis then only patches (W % 4 == 0: a lane stores its 4 pixels as one dword)
+  uint8_t *prov_out; u32 prov_pitch; size_t prov_fs;
   u32 wrap_limit;  // S >= wrap_limit: gradient >= 256, the wrap bands apply (0xFFFFFFFF: saturating variant)
 };
 
@@ -63,6 +66,7 @@ struct HystParams {
   size_t out_pitch, out_frame_stride;
   int W;
   int debug_skip;  // diagnostics: stage and write back only
+  int prov;        // the output already holds 255 for every strong pixel of the input planes (written by k_nms): launch 0 only rewrites rows it changes
   int first_pass;  // the planes come straight from k_front / k_pack: rows are not yet closed under the in-row fill
 };
 

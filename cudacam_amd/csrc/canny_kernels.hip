@@ -587,6 +587,7 @@ hipError_t launch_front(const FrontParams &p, hipStream_t s)
 // the L2 fetches every partially written line first: measured 2.6x read amplification).  Bytes 4..251 of a
 // segment row are the strip's own 248 columns; the two halo dwords are junk and never read: k_nms takes its
 // halo columns from the neighbouring strips' segments.
+static __device__ __forceinline__ u32 nibble_to_bytes(u32 nib);
 constexpr int BSUB = 24;   // blur rows between two fix-up passes of k_blur
 constexpr int BRING = 32;  // input rows (masked, grey) kept in a wave-private LDS ring for the fix-up: >= BSUB + 4, power of 2
 constexpr int BLUR_WAVE_BYTES = BRING * 256 + QCAP * 4;
@@ -937,6 +938,13 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
         pair(std::integral_constant<int, 0>{});
         nib = (nibS | (nibC << 8)) & oknib;
       }
+      if (p.prov_out && lane >= 1 && lane <= 62 && c0 < W) {  // provisional 0/255 map (strong bits); W % 4 == 0 here
+        u32 po;
+        asm("s_mul_i32 %0, %1, %2" : "=s"(po) : "s"(c), "s"(p.prov_pitch));
+        u32 o = (u32)(strip * STRIP_W + 4 * (lane - 1));
+        asm volatile("" : "+v"(o));
+        *reinterpret_cast<u32 *>(p.prov_out + (size_t)frame * p.prov_fs + po + o) = nibble_to_bytes(nib & 0xFu);
+      }
       const u32 w = nib | (from_lane_above(nib) << 4);
       if (store_lane) {
         u32 roff;
@@ -1148,6 +1156,13 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
         pair(std::integral_constant<int, 1>{});
         pair(std::integral_constant<int, 0>{});
         nib = (nibS | (nibC << 8)) & oknib;
+      }
+      if (p.prov_out && lane >= 1 && lane <= 62 && c0 < W) {  // provisional 0/255 map (strong bits); W % 4 == 0 here
+        u32 po;
+        asm("s_mul_i32 %0, %1, %2" : "=s"(po) : "s"(c), "s"(p.prov_pitch));
+        u32 o = (u32)(strip * STRIP_W + 4 * (lane - 1));
+        asm volatile("" : "+v"(o));
+        *reinterpret_cast<u32 *>(p.prov_out + (size_t)frame * p.prov_fs + po + o) = nibble_to_bytes(nib & 0xFu);
       }
       const u32 w = nib | (from_lane_above(nib) << 4);
       if (store_lane) {
@@ -1375,6 +1390,7 @@ void hyst_tile_geometry(int RD, bool beside_front, int *tile_rows, int *waves)
 template <int NW, int TR, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 {
+  static_assert(NW == 1, "frames wider than one panel are tiled in column panels; a lane holds one dword per row");
   if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
   // latency-bound kernel (a few waves walking dependent row steps): when it shares a SIMD with the next
   // run's k_front waves (pipelined mode) it should win the instruction arbitration
@@ -1581,35 +1597,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
     if (!more) break;
   }
 
-  // write back the rows that changed; tell the neighbouring workgroups through the tile flags
-  for (u64 m = changed; m; m &= m - 1) {
-    const int r = __builtin_ctzll(m);
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const int dd = pcol + lane * NW + j;
-      if (dd < RD) S[(size_t)(b0 + w0 + r) * RD + dd] = sr[j][r];
-    }
-  }
-  // fused expand (removeCandidates + output copy, cannyEdgeD.cu:379-395): strong bits -> 255, rest 0.
-  // 16 px per lane per store; launch 0 writes every row of the tile, later launches the changed ones.
-  if (p.out) {
+  // Rows that changed go back to the plane, and the 0/255 map is written (removeCandidates + output copy,
+  // cannyEdgeD.cu:379-395: strong bits -> 255, rest 0; 16 px per lane per store).  When the output already shows
+  // the planes as they were in memory -- k_nms wrote the strong pixels (p.prov), or an earlier launch left it so --
+  // only the 16-pixel groups whose bits changed are rewritten: the old dword of a row is read back (one row ahead)
+  // and compared before the new one is stored.
+  {
+    const bool patch = p.out && (p.iter > 0 || p.prov);
     const bool a16 = (((uintptr_t)p.out | p.out_pitch | p.out_frame_stride) & 15u) == 0;
-    uint8_t *obase = p.out + (size_t)frame * p.out_frame_stride;
-    for (u64 m = p.iter == 0 ? all_rows : changed; m; m &= m - 1) {
+    uint8_t *obase = p.out ? p.out + (size_t)frame * p.out_frame_stride : nullptr;
+    const bool in_panel = pcol + lane < RD;
+    u32 *Srow = S + (size_t)(b0 + w0) * RD + pcol + lane;  // this lane's dword of the wave's first row
+    u64 m = (p.out && !patch) ? all_rows : changed;
+    u32 oldn = 0;
+    if (patch && m && in_panel) oldn = Srow[(size_t)__builtin_ctzll(m) * RD];
+    while (m) {
       const int r = __builtin_ctzll(m);
+      m &= m - 1;
+      const u32 old = oldn;
+      if (patch && m && in_panel) oldn = Srow[(size_t)__builtin_ctzll(m) * RD];
+      const u32 rowv = sr[0][r];
+      u64 mlo = ~0ull, mhi = ~0ull;  // which half-words (16-pixel groups) of the row changed: bit L = dword L
+      if (patch) {
+        const u32 dv = old ^ rowv;
+        mlo = __ballot((dv & 0xFFFFu) != 0);
+        mhi = __ballot((dv >> 16) != 0);
+      }
+      if (((changed >> r) & 1ull) && in_panel) Srow[(size_t)r * RD] = rowv;
+      if (!p.out) continue;
       uint8_t *orow = obase + (size_t)(b0 + w0 + r) * p.out_pitch;
-      u32 rowv[NW];
-#pragma unroll
-      for (int j = 0; j < NW; ++j) rowv[j] = sr[j][r];
       for (int pass = 0; pass * 1024 < ROWW * 32 && pcol * 32 + pass * 1024 < p.W; ++pass) {
         // this lane writes px [32*pcol + 1024*pass + 16*lane, +16): half-word 64*pass + lane of the panel row
         const int D = 32 * pass + (lane >> 1);  // dword (of the panel) holding it
-        u32 x = 0;
-#pragma unroll
-        for (int j = 0; j < NW; ++j) {
-          const u32 t = __shfl(rowv[j], D / NW);
-          x = (D % NW) == j ? t : x;
-        }
+        const u32 x = __shfl(rowv, D);  // before any lane drops out: the permute only sees the values of active lanes
+        if (patch && ((((lane & 1) ? mhi : mlo) >> D) & 1ull) == 0) continue;  // this group of 16 pixels did not change
         const u32 b = (x >> (16 * (lane & 1))) & 0xFFFFu;
         const int c0 = pcol * 32 + pass * 1024 + lane * 16;
         if (c0 >= p.W) continue;

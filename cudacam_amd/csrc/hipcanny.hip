@@ -44,6 +44,7 @@ struct Slot {
   size_t copy_pitch = 0, copy_fs = 0;
   int n = 0;
   int k_launches = 0;            // hysteresis launches queued for this run
+  bool prov = false;             // this run's k_nms wrote the provisional output
   hipStream_t stream = nullptr;  // stream the hysteresis of this run was queued on
 };
 }  // namespace
@@ -239,6 +240,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   const int K = c->hyst_launches_set ? c->hyst_launches : std::min(MAX_HYST_LAUNCHES, std::max(c->hyst_launches, hp.nrtiles + hp.npanels));
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
+  hp.prov = s.prov ? 1 : 0;
   hp.debug_skip = getenv("HC_DEBUG_SKIP_HYST") ? 1 : 0;
   for (int k = 0; k < K; ++k) {
     hp.iter = k;
@@ -326,6 +328,12 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     fp.nstrips = c->nstrips; fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows; fp.nframes = n_out;
     fp.total_items = n_out * fp.nstrips * fp.nchunks;
     const bool split = c->split && c->mode == HC_MODE_R;
+    // Pipelined mode: k_nms / k_front_o also write the strong pixels as 255 into the output (4 px per lane: whole
+    // dwords need W % 4 == 0), so that the hysteresis, which runs beside the next run's bandwidth-hungry k_blur, only
+    // rewrites the 16-pixel groups it changes instead of streaming out the whole map (+8 % end to end; without the
+    // overlap the extra stores of the VALU-bound kernel cost more than the hysteresis saves).
+    s.prov = piped && W % 4 == 0 && (split || c->mode == HC_MODE_O);
+    if (s.prov) { fp.prov_out = dst; fp.prov_pitch = (u32)dp; fp.prov_fs = dfs; }
     if (split) {  // k_blur + k_nms through the blur plane
       if (int rc = ensure_blur_plane(c)) return rc;
       fp.blur = c->d_bplane; fp.blur_frame_stride = c->bplane_fs;
@@ -336,6 +344,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.run_rows_b = rows;
       fp.nchunks_b = (H + rows - 1) / rows;
       fp.total_items_b = n_out * fp.nstrips * fp.nchunks_b;
+
     }
     if (c->mode == HC_MODE_O) {
       // cv::Canny: plain thresholds on the L1 magnitude; long chunks (no LDS slab, 4-row warm-up)
