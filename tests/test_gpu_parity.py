@@ -290,30 +290,44 @@ def test_mode_o_l2gradient(oracle, name, make, low, high):
         _diff(ctx.process(img)[0], want, f"mode O L2 {name}")
 
 
-def test_pipelined_runs(oracle):
+@pytest.mark.parametrize("w,h,mode", [(500, 300, "R"), (641, 203, "R"), (4100, 150, "R"), (2052, 270, "R"), (500, 300, "O"), (4100, 150, "O")])
+def test_pipelined_runs(oracle, w, h, mode):
     """HC_OPT_PIPELINE: back-to-back device runs overlap (front of run i+1 / hysteresis of run i);
-    every run's output must still be exactly the oracle's after hc_sync."""
+    every run's output must still be exactly the oracle's after hc_sync.  Widths that are multiples of 4 take the
+    provisional-map path (k_nms / k_front_o write the strong pixels, the hysteresis patches 16-pixel groups), 641 does
+    not; 2052 and 4100 span several hysteresis panels."""
     import torch
-    w, h, nb = 500, 300, 3
+    nb = 3
     batches = [np.stack([synth.natural(w, h, 40 + 10 * r + f) for f in range(nb)]) for r in range(5)]
-    want = [oracle.canny_r_batch(b, 10, 40, threads=4) for b in batches]
-    d_in = [torch.from_numpy(b).cuda() for b in batches]
+    batches[3] = np.stack([synth.serpentine(w, h, amp=30 if mode == "O" else 20, seed_amp=200 if mode == "O" else 120) for f in range(nb)])  # long thin chains: many patches
+    if mode == "R":
+        want = [oracle.canny_r_batch(b, 10, 40, threads=4) for b in batches]
+    else:
+        want = [oracle.canny_o_batch(b, 50, 150, threads=4) for b in batches]
+    pitch = (w + 3) // 4 * 4
+    d_in = []
+    for b in batches:
+        buf = np.zeros((nb, h, pitch), np.uint8)
+        buf[:, :, :w] = b
+        d_in.append(torch.from_numpy(buf).cuda())
     d_out = [torch.zeros_like(t) for t in d_in]
-    with api.Context(w, h, 1, nb) as ctx:
+    with api.Context(w, h, 1, nb, api.MODE_R if mode == "R" else api.MODE_O) as ctx:
+        if mode == "O":
+            ctx.set_thresholds(50, 150)
         ctx.set_option(api.OPT_PIPELINE, 1)
         for rep in range(2):
             for r in range(5):
-                ctx.run_device(d_in[r].data_ptr(), w, w * h, d_out[r].data_ptr(), w, w * h, nb)
+                ctx.run_device(d_in[r].data_ptr(), pitch, pitch * h, d_out[r].data_ptr(), pitch, pitch * h, nb)
             ctx.sync()
             for r in range(5):
-                got = d_out[r].cpu().numpy()
+                got = d_out[r].cpu().numpy()[:, :, :w]
                 for f in range(nb):
                     _diff(got[f], want[r][f], f"pipelined rep {rep} run {r} frame {f}")
-                d_out[r].zero_()
+                d_out[r].fill_(rep + 7)   # stale bytes must not survive: the next pass rewrites (or patches) everything
         ctx.set_option(api.OPT_PIPELINE, 0)
-        ctx.run_device(d_in[0].data_ptr(), w, w * h, d_out[0].data_ptr(), w, w * h, nb)
+        ctx.run_device(d_in[0].data_ptr(), pitch, pitch * h, d_out[0].data_ptr(), pitch, pitch * h, nb)
         ctx.sync()
-        _diff(d_out[0].cpu().numpy()[1], want[0][1], "plain mode after pipelined mode")
+        _diff(d_out[0].cpu().numpy()[1, :, :w], want[0][1], "plain mode after pipelined mode")
 
 
 def test_python_mirror_of_reference_operator(oracle):
