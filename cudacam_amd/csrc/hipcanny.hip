@@ -72,7 +72,7 @@ struct hc_ctx {
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
   size_t bplane_fs = 0, bplane_frames = 0;
   int RD = 0;
-  int nstrips = 0, chunk = 0, hyst_launches = 6, hyst_waves = 8;
+  int nstrips = 0, chunk = 0, hyst_launches = 6;
   bool hyst_launches_set = false;  // hc_set_tuning called: queue exactly that many launches
   int last_work_launches = 0, last_continued = 0;
   u32 h_stats[3 * 16] = { 0 };
@@ -483,7 +483,6 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     for (int i = 0; i < 25; ++i) { volatile float k = (float)K[i]; volatile float v = k * r; gk[i] = v; }
     good = ok(upload_gauss_coeffs(gk), "hipMemcpyToSymbol(GK)");
   }
-  if (const char *e = getenv("HC_HYST_WAVES")) { const int w = atoi(e); if (w == 4 || w == 8 || w == 16) c->hyst_waves = w; }
   if (!good) { hc_destroy(c); return nullptr; }
   return c;
 }
