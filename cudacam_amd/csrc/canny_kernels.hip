@@ -588,8 +588,13 @@ hipError_t launch_front(const FrontParams &p, hipStream_t s)
 // segment row are the strip's own 248 columns; the two halo dwords are junk and never read: k_nms takes its
 // halo columns from the neighbouring strips' segments.
 static __device__ __forceinline__ u32 nibble_to_bytes(u32 nib);
-constexpr int BSUB = 24;   // blur rows between two fix-up passes of k_blur
-constexpr int BRING = 32;  // input rows (masked, grey) kept in a wave-private LDS ring for the fix-up: >= BSUB + 4, power of 2
+#ifndef HC_BSUB
+#define HC_BSUB 24
+#define HC_BRING 32
+#define HC_BG 8
+#endif
+constexpr int BSUB = HC_BSUB;   // blur rows between two fix-up passes of k_blur
+constexpr int BRING = HC_BRING;  // input rows (masked, grey) kept in a wave-private LDS ring for the fix-up: >= BSUB + 4, power of 2
 constexpr int BLUR_WAVE_BYTES = BRING * 256 + QCAP * 4;
 
 // the literal reference chain (cannyEdgeD.cu:102-115) on the LDS ring: rows and columns outside the image
@@ -727,8 +732,8 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
   // The kernel is bound by memory latency, not arithmetic (a row is ~60 VALU ops): the G rows of the next
   // group are requested before the current group is processed.  (The compiler drains the memory counter
   // once per loop trip, vmcnt(0), so loads issued inside the group would be waited for almost at once.)
-  constexpr int G = 8;
-  static_assert(BSUB % G == 0, "fix-up windows are whole groups");
+  constexpr int G = HC_BG;
+  static_assert(BSUB % G == 0 && BRING >= BSUB + 4 && (BRING & (BRING - 1)) == 0, "fix-up windows are whole groups; the ring holds a window and its 4 halo rows");
   {  // warm-up: input rows r0-2 .. r0+1 only feed the accumulators
     u32 xw[4];
 #pragma unroll
