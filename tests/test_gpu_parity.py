@@ -381,3 +381,31 @@ def test_context_reuse_sequences(oracle):
         got = d_out.cpu().numpy()
         for f in range(8):
             _diff(got[f], oracle.canny_r(allf[f], 10, 40), f"pipelined device runs, frame {f}")
+
+
+def test_two_contexts_from_two_threads(oracle):
+    """Contexts are independent (include/hipcanny.h): two of them, different sizes and modes, driven from two threads."""
+    import threading
+    jobs = [(synth.natural(900, 400, 5), "R", 10, 40), (synth.noise(640, 333, 6), "O", 60, 180)]
+    want = [oracle.canny_r(jobs[0][0], 10, 40), oracle.canny_o(jobs[1][0], 60, 180)]
+    errs = []
+
+    def work(k):
+        img, mode, lo, hi = jobs[k]
+        try:
+            with api.Context(img.shape[1], img.shape[0], 1, 2, api.MODE_R if mode == "R" else api.MODE_O) as ctx:
+                ctx.set_thresholds(lo, hi)
+                for _ in range(25):
+                    got = ctx.process(np.stack([img, img]))
+                    if not (np.array_equal(got[0], want[k]) and np.array_equal(got[1], want[k])):
+                        errs.append(f"context {k}: mismatch")
+                        return
+        except Exception as e:  # noqa: BLE001
+            errs.append(f"context {k}: {e!r}")
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
