@@ -9,6 +9,43 @@
 
 #include <cstdlib>
 
+// ---- timerManager (include/cvp/timer.hpp) -------------------------------------------------------------------
+float timer::averageTime() const { return nbCount ? static_cast<float>(totalTime / static_cast<double>(nbCount)) : 0.0f; }
+
+timerManager &timerManager::Get()
+{
+  static timerManager table;
+  return table;
+}
+
+const timer *timerManager::lookup(const std::string &name) const
+{
+  const auto hit = m_timers.find(name);
+  if (hit != m_timers.end()) return &hit->second;
+  LOG_ERROR("Timer {} unknown", name);
+  return nullptr;
+}
+
+void timerManager::createTimer(std::string name) { m_timers.emplace(std::move(name), timer{}); }
+
+void timerManager::addTime(std::string name, double time)
+{
+  if (lookup(name) == nullptr) return;
+  timer &slot = m_timers.find(name)->second;
+  slot.totalTime += time;
+  ++slot.nbCount;
+}
+
+double timerManager::getAverageTime(std::string name) const
+{
+  const timer *t = lookup(name);
+  if (t && t->nbCount == 0) LOG_ERROR("Timer {} unknown", name);  // the reference reports an empty timer the same way
+  return (t && t->nbCount) ? t->totalTime / static_cast<double>(t->nbCount) : 0.0;
+}
+
+timerManager::TimerMap::const_iterator timerManager::beginTimerList() const { return m_timers.cbegin(); }
+timerManager::TimerMap::const_iterator timerManager::endTimerList() const { return m_timers.cend(); }
+
 namespace cvp
 {
 namespace cuda
@@ -92,7 +129,7 @@ namespace cuda
 }// namespace cuda
 
 cvPipeline::cvPipeline(const unsigned int pbo, const unsigned int inputImageCols, const unsigned int inputImageRows, const int inputImageNbChannels)
-  : m_cudaCannyEdge(std::make_unique<cuda::CannyEdge>(pbo, inputImageCols, inputImageRows, inputImageNbChannels))
+  : m_detector(std::make_unique<cuda::CannyEdge>(pbo, inputImageCols, inputImageRows, inputImageNbChannels))
 {
 }
 
@@ -101,7 +138,7 @@ cvPipeline::~cvPipeline() = default;
 
 bool cvPipeline::process(cv::Mat inputImage, CannyStage finalStage)
 {
-  if (!m_cudaCannyEdge) {
+  if (!m_detector) {
     LOG_ERROR("Cannot process the webcam stream, device is not ready.");
     return false;
   }
@@ -113,33 +150,33 @@ bool cvPipeline::process(cv::Mat inputImage, CannyStage finalStage)
     LOG_ERROR("Only supporting CV_8UC3 and CV_8UC1 input types for now");
     return false;
   }
-  m_cudaCannyEdge->run(inputImage, finalStage);
+  m_detector->run(inputImage, finalStage);
   return true;
 }
 
 void cvPipeline::setLowThreshold(unsigned char low)
 {
-  if (m_cudaCannyEdge) m_cudaCannyEdge->setLowThreshold(low);
+  if (m_detector) m_detector->setLowThreshold(low);
   else LOG_ERROR("Cannot modify low threshold, device is not ready.");
 }
 
-unsigned char cvPipeline::getLowThreshold() const { return m_cudaCannyEdge ? m_cudaCannyEdge->getLowThreshold() : 0; }
+unsigned char cvPipeline::getLowThreshold() const { return m_detector ? m_detector->getLowThreshold() : 0; }
 
 void cvPipeline::setHighThreshold(unsigned char high)
 {
-  if (m_cudaCannyEdge) m_cudaCannyEdge->setHighThreshold(high);
+  if (m_detector) m_detector->setHighThreshold(high);
   else LOG_ERROR("Cannot modify high threshold, device is not ready.");
 }
 
-unsigned char cvPipeline::getHighThreshold() const { return m_cudaCannyEdge ? m_cudaCannyEdge->getHighThreshold() : 255; }
+unsigned char cvPipeline::getHighThreshold() const { return m_detector ? m_detector->getHighThreshold() : 255; }
 
 void cvPipeline::enableCudaProfiling(bool profiling)
 {
-  if (m_cudaCannyEdge) m_cudaCannyEdge->enableKernelProfiling(profiling);
+  if (m_detector) m_detector->enableKernelProfiling(profiling);
   else LOG_ERROR("Cannot modify profiling, device is not ready.");
 }
 
-bool cvPipeline::isCudaProfilingEnabled() const { return m_cudaCannyEdge ? m_cudaCannyEdge->isKernelProfilingEnabled() : false; }
+bool cvPipeline::isCudaProfilingEnabled() const { return m_detector ? m_detector->isKernelProfilingEnabled() : false; }
 
-const std::vector<std::uint8_t> &cvPipeline::output() const { return m_cudaCannyEdge->output(); }
+const std::vector<std::uint8_t> &cvPipeline::output() const { return m_detector->output(); }
 }// namespace cvp

@@ -1,43 +1,50 @@
-// include/cvp/cvPipeline.hpp -- cvp::cvPipeline, the "pure cpp proxy" the UI talks to.
-// Signatures as in the reference (src/cvp/cvPipeline.hpp:20-39); behaviour as in
-// src/cvp/cvPipeline.cpp:19-96 (false for blank frames and for types other than CV_8UC1 / CV_8UC3).
+// include/cvp/cvPipeline.hpp -- cvp::cvPipeline: the host-only proxy CudaCam's UI owns (src/imgui/imguiApp.cpp:102)
+// and calls once per camera frame (imguiApp.cpp:515).  Every public member keeps the reference's name, argument
+// list and meaning (src/cvp/cvPipeline.hpp:20-39), so the UI sources compile against this header unchanged; the body
+// (cudacam_amd/csrc/cvp_host.cpp) forwards to the MI355X detector instead of the CUDA one.
 #pragma once
 
 #include <cstdint>
 #include <memory>
 #include <vector>
 
-#include "cvmat_min.hpp"
-#include "define.hpp"
+#include "cvmat_min.hpp"  // cv::Mat: OpenCV's when available, a minimal stand-in otherwise
+#include "define.hpp"     // cvp::CannyStage
 
 namespace cvp
 {
 namespace cuda
 {
-  class CannyEdge;
+  class CannyEdge;  // defined in cannyEdgeH.hpp; kept out of this header as in the reference
 }
 
 class cvPipeline
 {
 public:
-  cvPipeline(const unsigned int pbo, const unsigned int inputImageCols, const unsigned int inputImageRows, const int inputImageNbChannels);
+  // pbo: GL pixel-buffer id of the reference's display path; must be 0 here (no GL on a headless MI355X, see output()).
+  // cols / rows / channels: geometry of every frame that will be processed (CV_8UC1 or CV_8UC3).
+  cvPipeline(unsigned int pbo, unsigned int inputImageCols, unsigned int inputImageRows, int inputImageNbChannels);
   ~cvPipeline();
 
+  // One frame through the detector up to `finalStage`.  Returns false -- and logs, as src/cvp/cvPipeline.cpp:27-36
+  // does -- for an empty frame or a type other than CV_8UC1 / CV_8UC3; true otherwise.
   bool process(cv::Mat inputImage, CannyStage finalStage);
 
-  void setLowThreshold(unsigned char low);
+  // Double-threshold limits, clamped against each other (src/cvp/cannyEdgeH.hpp:25-29).
   unsigned char getLowThreshold() const;
-
-  void setHighThreshold(unsigned char high);
   unsigned char getHighThreshold() const;
+  void setLowThreshold(unsigned char low);
+  void setHighThreshold(unsigned char high);
 
-  void enableCudaProfiling(bool profiling);
+  // Per-stage timers (timerManager entries named by cvp::CANNY_STAGES); on by default like the reference.
   bool isCudaProfilingEnabled() const;
+  void enableCudaProfiling(bool profiling);
 
-  // display-less addition: the image the reference would have left in the GL PBO
+  // Not in the reference: the tight width x height u8 image of the last processed frame -- what the reference leaves
+  // in the GL pixel buffer (src/cvp/cannyEdgeH.cu:154-212).
   const std::vector<std::uint8_t> &output() const;
 
 private:
-  std::unique_ptr<cuda::CannyEdge> m_cudaCannyEdge;
+  std::unique_ptr<cuda::CannyEdge> m_detector;
 };
 }// namespace cvp
