@@ -409,3 +409,30 @@ def test_two_contexts_from_two_threads(oracle):
     for t in th:
         t.join()
     assert not errs, errs
+
+
+@pytest.mark.parametrize("per_channel", [0, 1])
+def test_pipelined_three_channel_runs(oracle, per_channel):
+    """Pipelined device runs on interleaved 3-channel input: grey conversion fused into k_blur, or one map per channel
+    (3 output frames per input frame; the provisional map is written per output frame)."""
+    import torch
+    w, h, nb = 520, 260, 2
+    rng = np.random.default_rng(77)
+    batches = [np.stack([np.stack([synth.natural(w, h, 300 + 7 * r + 3 * f + c) for c in range(3)], axis=-1) for f in range(nb)]) for r in range(4)]
+    if per_channel:
+        want = [np.stack([oracle.canny_r(np.ascontiguousarray(b[f, :, :, c]), 10, 40) for f in range(nb) for c in range(3)]) for b in batches]
+    else:
+        want = [np.stack([oracle.canny_r(b[f], 10, 40) for f in range(nb)]) for b in batches]
+    d_in = [torch.from_numpy(b).cuda() for b in batches]
+    n_out = nb * (3 if per_channel else 1)
+    d_out = [torch.full((n_out, h, w), 9, dtype=torch.uint8, device="cuda") for _ in batches]
+    with api.Context(w, h, 3, nb) as ctx:
+        ctx.set_option(api.OPT_PER_CHANNEL, per_channel)
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        for r in range(4):
+            ctx.run_device(d_in[r].data_ptr(), 3 * w, 3 * w * h, d_out[r].data_ptr(), w, w * h, nb)
+        ctx.sync()
+        for r in range(4):
+            got = d_out[r].cpu().numpy()
+            for f in range(n_out):
+                _diff(got[f], want[r][f], f"3-channel pipelined (per_channel {per_channel}) run {r} map {f}")
