@@ -4,13 +4,15 @@
 // launch sites src/cvp/cannyEdgeH.cu:214-338) is done here in
 //   k_blur + k_nms (or the fused k_front)   blur | Sobel + magnitude + direction + NMS + double threshold -> 2 bit planes
 //   k_hyst    edge hysteresis on the bit planes (64 px per 64-bit op), device-side convergence flag,
-//             0/255 u8 edge map written by the same kernel
+//             0/255 u8 edge map written (or, after k_nms's provisional map, patched) by the same kernel
+//   k_front_o the cv::Canny ("Mode O") counterpart of the front path, one pass
+// plus the plain per-stage kernels behind the finalStage taps and k_pack for hc_hysteresis_device.
 // MFMA is deliberately not used: there is no dense contraction (an f32 MFMA would reproduce the
 // Gaussian's fmaf chain bit for bit, but as a banded 36x32 Toeplitz product it wastes 31/36 of its
 // multiplies and runs at the f32 vector rate -- 4-7x slower than the packed integer form below).
 //
 // Numerical contract ("Mode R"): identical to the reference kernels, including the
-// float Gaussian chain (via the exact shortcut explained at gauss_row), the u8 wrap of gradients
+// float Gaussian chain (via the exact integer shortcut explained in k_front / k_blur), the u8 wrap of gradients
 // >= 256 and the non-strict NMS.
 #include "canny_common.h"
 #include <cstdio>
