@@ -89,7 +89,10 @@ def main():
     reps = (B + d_u.shape[0] - 1) // d_u.shape[0]
     d_in = d_u.repeat(*([reps] + [1] * (d_u.dim() - 1)))[:B].contiguous()   # (B, H, W[, 3]) u8, tight pitch
     n_out = 3 * B if a.per_channel else B
-    d_out = torch.empty((n_out, H, W), dtype=torch.uint8, device=dev)
+    # two output batches used in turn, as a pipelined consumer would (run i's maps are read while run i+1 computes);
+    # with a single one the library falls back to the non-provisional expand to keep run i+1's map intact
+    d_outs = [torch.empty((n_out, H, W), dtype=torch.uint8, device=dev) for _ in range(1 if a.no_pipeline else 2)]
+    d_out = d_outs[0]
     del d_u
 
     ctx = api.Context(W, H, C, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local)
@@ -103,8 +106,12 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)
 
+    nstep = [0]
+
     def step():
-        ctx.run_device(d_in.data_ptr(), W * C, W * C * H, d_out.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
+        o = d_outs[nstep[0] % len(d_outs)]
+        nstep[0] += 1
+        ctx.run_device(d_in.data_ptr(), W * C, W * C * H, o.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
 
     for _ in range(a.warmup):
         step()
@@ -151,6 +158,7 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": f"synthetic ({a.kind}, {min(a.unique, B)} distinct frames tiled to the batch)",
+            "output_buffers": len(d_outs),
             "config": {"workload": (f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU" if (W, H, a.mode) == (1920, 1080, "R")
                                     else f"{W}x{H} " + ("grayscale" if C == 1 else "BGR, per-channel Canny" if a.per_channel else "BGR -> grey") + f", mode {a.mode}, batch {B} frames/step/GPU"),
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",

@@ -68,6 +68,7 @@ struct hc_ctx {
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
   int split = 1;        // front path as k_blur + k_nms (default) or the fused k_front
+  uintptr_t prev_out0 = 0, prev_out1 = 0;  // output range of the previous pipelined run (provisional-map hazard check)
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
   size_t bplane_fs = 0, bplane_frames = 0;
@@ -223,7 +224,9 @@ int finish_all(hc_ctx *c)
 {
   // oldest first
   if (int rc = finish_slot(c, c->slot[c->cur])) return rc;
-  return finish_slot(c, c->slot[c->cur ^ 1]);
+  if (int rc = finish_slot(c, c->slot[c->cur ^ 1])) return rc;
+  c->prev_out0 = c->prev_out1 = 0;  // nothing is in flight any more
+  return HC_OK;
 }
 
 // bit planes of slot s -> fixpoint -> u8 image, queued on `st`
@@ -332,7 +335,12 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     // dwords need W % 4 == 0), so that the hysteresis, which runs beside the next run's bandwidth-hungry k_blur, only
     // rewrites the 16-pixel groups it changes instead of streaming out the whole map (+8 % end to end; without the
     // overlap the extra stores of the VALU-bound kernel cost more than the hysteresis saves).
-    s.prov = piped && W % 4 == 0 && (split || c->mode == HC_MODE_O);
+    // Not when this run's output overlaps the previous run's (a caller that keeps one output buffer): that run's
+    // hysteresis may still be patching it, and a late patch would survive into this run's map.
+    const uintptr_t o0 = (uintptr_t)dst, o1 = o0 + (size_t)n_out * dfs;
+    const bool out_overlap = piped && c->prev_out0 < o1 && o0 < c->prev_out1;
+    s.prov = piped && !out_overlap && W % 4 == 0 && (split || c->mode == HC_MODE_O);
+    if (piped) { c->prev_out0 = o0; c->prev_out1 = o1; }
     if (s.prov) { fp.prov_out = dst; fp.prov_pitch = (u32)dp; fp.prov_fs = dfs; }
     if (split) {  // k_blur + k_nms through the blur plane
       if (int rc = ensure_blur_plane(c)) return rc;

@@ -436,3 +436,24 @@ def test_pipelined_three_channel_runs(oracle, per_channel):
             got = d_out[r].cpu().numpy()
             for f in range(n_out):
                 _diff(got[f], want[r][f], f"3-channel pipelined (per_channel {per_channel}) run {r} map {f}")
+
+
+def test_pipelined_runs_into_one_output_buffer(oracle):
+    """A caller that hands every pipelined run the same output buffer loses the earlier maps, but after hc_sync the
+    buffer must hold the LAST run's map exactly: no late patch of an earlier run's hysteresis may survive in it
+    (the library drops the provisional-map shortcut when consecutive outputs overlap)."""
+    import torch
+    w, h, nb = 600, 320, 2
+    runs = [np.stack([synth.natural(w, h, 500 + 13 * r + f) for f in range(nb)]) for r in range(6)]
+    runs[4] = np.stack([synth.serpentine(w, h) for _ in range(nb)])
+    d_in = [torch.from_numpy(b).cuda() for b in runs]
+    d_out = torch.zeros((nb, h, w), dtype=torch.uint8, device="cuda")
+    with api.Context(w, h, 1, nb) as ctx:
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        for last in (5, 3):
+            for r in range(last + 1):
+                ctx.run_device(d_in[r].data_ptr(), w, w * h, d_out.data_ptr(), w, w * h, nb)
+            ctx.sync()
+            got = d_out.cpu().numpy()
+            for f in range(nb):
+                _diff(got[f], oracle.canny_r(runs[last][f], 10, 40), f"one output buffer, last run {last}, frame {f}")
