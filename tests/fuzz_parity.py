@@ -5,6 +5,7 @@ import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))  # repo root
 from cudacam_amd import api, synth
+api.preload_hip_runtime()
 from oracle import oracle as O
 
 O.build()
@@ -57,6 +58,34 @@ for i in range(cases):
         n_in = ctx.upload(frames)
         ctx.run(api.CannyStage.HYSTER, n_in)
         got = ctx.download(len(want))
+    if ch == 1 and rng.random() < 0.35:
+        # the same case once more through the pipelined device path: three runs in a row (the frames rolled
+        # differently each time) into two output buffers used in turn; the last two maps are checked
+        import torch
+        pitch = (w + 3) // 4 * 4
+        def dev(fr):
+            buf = np.zeros((nb, h, pitch), np.uint8); buf[:, :, :w] = fr
+            return torch.from_numpy(buf).cuda()
+        seq = [np.stack([np.roll(f, 7 * (r + 1), axis=0) for f in frames]) for r in range(3)]
+        d_in = [dev(fr) for fr in seq]
+        d_o = [torch.full((nb, h, pitch), 3, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        with api.Context(w, h, 1, nb, api.MODE_R if mode == "R" else api.MODE_O) as ctx:
+            ctx.set_thresholds(low, high)
+            if mode == "R":
+                ctx.set_option(api.OPT_NMS_SATURATE, opts["sat"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)
+            else:
+                ctx.set_option(api.OPT_L2_GRADIENT, opts["l2"])
+            ctx.set_option(api.OPT_PIPELINE, 1)
+            for r in range(3):
+                ctx.run_device(d_in[r].data_ptr(), pitch, pitch * h, d_o[r % 2].data_ptr(), pitch, pitch * h, nb)
+            ctx.sync()
+        for r in (1, 2):
+            g = d_o[r % 2].cpu().numpy()[:, :, :w]
+            wnt = np.stack([O.canny_r(f, low, high, saturate=bool(opts["sat"])) if mode == "R" else O.canny_o(f, low, high, l2gradient=bool(opts["l2"])) for f in seq[r]])
+            if not np.array_equal(g, wnt):
+                bad += 1
+                print(f"MISMATCH (pipelined run {r}) case {i}: {w}x{h} {kind} seed {seed} mode {mode} thr {low}/{high} nb {nb} {opts}", flush=True)
+                break
     if not np.array_equal(got, want):
         bad += 1
         d = np.argwhere(got != want)
