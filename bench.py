@@ -131,6 +131,7 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     ctx.sync()                      # also verifies hysteresis convergence of the last step
+    ksums, kruns = ctx.profile_get_front()
     sums, nruns = ctx.profile_get(reset=True)
     work_launches, continued = ctx.hysteresis_info()
 
@@ -167,7 +168,9 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": ("k_front" if a.fused else "k_blur+k_nms") if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(achieved / HBM_MEASURED_COPY_GBPS, 4),
-                "traffic": None, "kernel_ms": round(front_ms, 4), "hyst_expand_ms": round(hyst_ms, 4), "launches_timed": nruns,
+                "traffic": None, "kernel_ms": round(front_ms, 4),
+                "kernel_ms_each": ({"k_blur": round(ksums[0] / kruns, 4), "k_nms": round(ksums[1] / kruns, 4)} if kruns else None),
+                "hyst_expand_ms": round(hyst_ms, 4), "launches_timed": nruns,
             },
             "hysteresis": {"launches_with_work": work_launches, "continued": continued},
         }

@@ -50,7 +50,7 @@ ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
-    "hc_host_alloc", "hc_host_free",
+    "hc_host_alloc", "hc_host_free", "hc_profile_get_front",
 ]
 
 _lib = None
@@ -102,6 +102,7 @@ def load_library():
     L.hc_enable_profiling.argtypes = [vp, i]
     L.hc_stage_time_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
     L.hc_profile_get.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), i]
+    L.hc_profile_get_front.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)]
     L.hc_device_ptrs.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.hc_last_hysteresis_info.argtypes = [vp, C.POINTER(i), C.POINTER(i)]
     L.hc_hysteresis_stats.argtypes = [vp, C.POINTER(C.c_uint), i]
@@ -179,6 +180,14 @@ class Context:
         n = C.c_long()
         _ck(self.lib.hc_profile_get(self.handle, sums, C.byref(n), int(bool(reset))))
         return [sums[0], sums[1], sums[2]], n.value
+
+    def profile_get_front(self):
+        """([k_blur_ms_sum, k_nms_ms_sum], nruns) of the profiled runs that took the split front path; call before
+        profile_get(reset=True)."""
+        sums = (C.c_double * 2)()
+        n = C.c_long()
+        _ck(self.lib.hc_profile_get_front(self.handle, sums, C.byref(n)))
+        return [sums[0], sums[1]], n.value
 
     def upload(self, frames):
         """frames: (n,H,W) / (n,H,W,3) uint8, or a single frame."""

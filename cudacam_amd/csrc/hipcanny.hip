@@ -84,7 +84,11 @@ struct hc_ctx {
   std::vector<hipEvent_t> evpool;
   int ev_head = 0, ev_count = 0;  // runs recorded since the last collect
   float stage_ms[6] = { 0, 0, 0, 0, 0, 0 };
+  static constexpr int EV_PER_RUN = 5;  // start, after stage 0, after the front kernels, end, between k_blur and k_nms
   double prof_sum[3] = { 0, 0, 0 };
+  double prof_split_sum[2] = { 0, 0 };  // k_blur, k_nms (split front path only)
+  long prof_split_runs = 0;
+  std::vector<char> ev_has_mid;         // per ring entry: event 4 was recorded
   long prof_runs = 0;
 };
 
@@ -295,7 +299,9 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   const bool prof = c->profiling && c->ev_count < hc_ctx::EV_RUNS;  // ring full: this run goes untimed
   hipEvent_t *ev = nullptr;
   if (prof) {
-    ev = &c->evpool[(size_t)((c->ev_head + c->ev_count) % hc_ctx::EV_RUNS) * 4];
+    const size_t slot_i = (size_t)((c->ev_head + c->ev_count) % hc_ctx::EV_RUNS);
+    ev = &c->evpool[slot_i * hc_ctx::EV_PER_RUN];
+    c->ev_has_mid[slot_i] = 0;
     HIPCK(hipEventRecord(ev[0], sf));
   }
   // stage 0 (cannyEdgeH.cu:214-227); 1-channel input skips it (the reference's mono path is broken, SURVEY §3 ii)
@@ -375,6 +381,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
       if (split) {
         HIPCK(launch_blur(fp, sf));
+        if (prof) {
+          HIPCK(hipEventRecord(ev[4], sf));
+          c->ev_has_mid[(size_t)(ev - c->evpool.data()) / hc_ctx::EV_PER_RUN] = 1;
+        }
         HIPCK(launch_nms(fp, sf));
       } else HIPCK(launch_front(fp, sf));
     }
@@ -481,7 +491,8 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch) == HC_OK;
   if (good && channels == 3) good = alloc_frames(&c->d_mono, &c->mono_pitch, &c->mono_fs, (size_t)width, height, max_batch) == HC_OK;
   good = good && alloc_slot(c, c->slot[0]) == HC_OK;
-  c->evpool.assign((size_t)hc_ctx::EV_RUNS * 4, nullptr);
+  c->evpool.assign((size_t)hc_ctx::EV_RUNS * hc_ctx::EV_PER_RUN, nullptr);
+  c->ev_has_mid.assign((size_t)hc_ctx::EV_RUNS, 0);
   for (size_t i = 0; good && i < c->evpool.size(); ++i) good = ok(hipEventCreate(&c->evpool[i]), "hipEventCreate");
   if (good) {
     // cannyEdgeH.cu:372-380: float coefficients K * (1 / 159.0f), computed in binary32 on the host
@@ -649,11 +660,18 @@ int hc_sync(hc_ctx *c)
   HIPCK(hipStreamSynchronize(c->s_hyst));
   HIPCK(hipStreamSynchronize(c->stream));
   while (c->ev_count > 0) {  // collect the event pairs of every run recorded since the last sync
-    hipEvent_t *e = &c->evpool[(size_t)c->ev_head * 4];
+    hipEvent_t *e = &c->evpool[(size_t)c->ev_head * hc_ctx::EV_PER_RUN];
     float a = 0, b = 0, d = 0;
     HIPCK(hipEventElapsedTime(&a, e[0], e[1]));
     HIPCK(hipEventElapsedTime(&b, e[1], e[2]));
     HIPCK(hipEventElapsedTime(&d, e[2], e[3]));
+    if (c->ev_has_mid[(size_t)c->ev_head]) {
+      float kb = 0, kn = 0;
+      HIPCK(hipEventElapsedTime(&kb, e[1], e[4]));
+      HIPCK(hipEventElapsedTime(&kn, e[4], e[2]));
+      c->prof_split_sum[0] += kb; c->prof_split_sum[1] += kn;
+      c->prof_split_runs++;
+    }
     for (float &m : c->stage_ms) m = 0;
     c->stage_ms[HC_STAGE_MONO] = a;
     c->stage_ms[HC_STAGE_THRESH] = b;
@@ -691,7 +709,19 @@ int hc_profile_get(hc_ctx *c, double sum_ms[3], long *nruns, int reset)
   if (int rc = hc_sync(c)) return rc;
   if (sum_ms) for (int i = 0; i < 3; ++i) sum_ms[i] = c->prof_sum[i];
   if (nruns) *nruns = c->prof_runs;
-  if (reset) { c->prof_sum[0] = c->prof_sum[1] = c->prof_sum[2] = 0; c->prof_runs = 0; }
+  if (reset) {
+    c->prof_sum[0] = c->prof_sum[1] = c->prof_sum[2] = 0; c->prof_runs = 0;
+    c->prof_split_sum[0] = c->prof_split_sum[1] = 0; c->prof_split_runs = 0;
+  }
+  return HC_OK;
+}
+
+int hc_profile_get_front(hc_ctx *c, double sum_ms[2], long *nruns)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (int rc = hc_sync(c)) return rc;
+  if (sum_ms) { sum_ms[0] = c->prof_split_sum[0]; sum_ms[1] = c->prof_split_sum[1]; }
+  if (nruns) *nruns = c->prof_split_runs;
   return HC_OK;
 }
 

@@ -96,6 +96,9 @@ int hc_stage_time_ms(hc_ctx *ctx, int stage, float *ms);
  * syncs): sum_ms[0] stage 0, [1] fused front kernel (or the tap kernels), [2] hysteresis + expand.
  * This is the accumulating counterpart of timerManager::addTime (src/utils/timer.hpp:27-39). */
 int hc_profile_get(hc_ctx *ctx, double sum_ms[3], long *nruns, int reset);
+/* The front path's two kernels separately, over the same profiled runs (those that took the split path):
+ * sum_ms[0] k_blur, [1] k_nms.  Read it before hc_profile_get(..., reset = 1), which clears both. */
+int hc_profile_get_front(hc_ctx *ctx, double sum_ms[2], long *nruns);
 
 /* Internal device buffers (input frames, output images) and their pitch / frame stride. */
 int hc_device_ptrs(hc_ctx *ctx, void **d_in, void **d_out, size_t *in_pitch, size_t *out_pitch, size_t *in_frame_stride,
