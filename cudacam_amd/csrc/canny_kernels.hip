@@ -794,10 +794,22 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
   }
 }
 
+// The NMS of the rare candidate pixels is queued (see "NMS queue" in the kernel): entries per wave and their size
+#ifndef HC_NQ_INLINE
+#define HC_NQ_INLINE 16  // a row with more queued lanes than this runs the NMS wave-wide instead
+#endif
+constexpr int NQ_INLINE = HC_NQ_INLINE;
+constexpr int NQ_CAP = 64 + NQ_INLINE;  // a batch is taken as soon as 64 entries wait, so at most 63 + NQ_INLINE are ever queued
+constexpr int NQ_DW = 24;               // dwords per entry: 3 x 6 S values, 2 X pairs, 2 Y pairs, (row, lane), pad
+constexpr int NMS_WAVE_BYTES = NQ_CAP * NQ_DW * 4;
+static_assert(NQ_CAP % 2 == 0 && NQ_INLINE % 2 == 0, "entries come in lane pairs");
+
 __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
 {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
+  u32 *nq = reinterpret_cast<u32 *>(smem + wib * NMS_WAVE_BYTES);  // wave-private
   const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
   if (item >= p.total_items_b) return;
   const int chunk = item % p.nchunks_b;
@@ -854,6 +866,71 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
   const u32 a_lo0 = p.a_lo[0], a_hi0 = p.a_hi[0], wrap_limit = p.wrap_limit;
   const u32 plane_pitch = (u32)p.RD * 4u;
 
+  // ---- NMS queue ------------------------------------------------------------------------------------------------
+  // About 5 % of the pixels pass the low threshold and 6 % of the lanes hold one, yet three wave-rows in four contain
+  // some: a wave-wide NMS spends nearly all of its lanes on pixels that are dropped anyway.  Instead a lane with a
+  // candidate -- and its partner in the output byte, lanes 2j+1 / 2j+2 -- parks what the NMS needs (the 3 x 6 S
+  // values around its 4 pixels, the Sobel sums of the centre row, its row and lane) in a wave-private LDS queue;
+  // once 64 entries wait, one dense pass does them, an entry per lane, and stores their bytes.  All other bytes
+  // of a row are written as zeros straight away.  A row with many candidates (a horizontal edge) runs wave-wide.
+  int qhead = 0, qcount = 0;  // wave-uniform; both even
+  auto nms_batch = [&](int nent) {
+    wave_lds_sync();
+    int idx = qhead + lane;
+    if (idx >= NQ_CAP) idx -= NQ_CAP;
+    const bool live = lane < nent;  // the other lanes compute on stale entries and store nothing
+    u32 v[NQ_DW];
+    const uint4 *ent = reinterpret_cast<const uint4 *>(nq + idx * NQ_DW);
+#pragma unroll
+    for (int j = 0; j < NQ_DW / 4; ++j) {
+      const uint4 t = ent[j];
+      v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    }
+    const u32 *SU = v, *SC = v + 6, *SN = v + 12;  // S rows above / at / below, [0] and [5] the neighbouring lanes' pixels
+    const u32 gmax = max(max(SC[1], SC[2]), max(SC[3], SC[4]));
+    const bool wraps = __ballot(live && gmax >= wrap_limit) != 0;
+    u32 nibS = 0, nibC = 0;
+    auto px = [&](auto hc, auto ec, u32 A2, u32 Um, u32 Vp) {
+      constexpr int e = decltype(ec)::value, q = 2 * decltype(hc)::value + e;
+      const u32 g = SC[1 + q];
+      bool cand = g >= a_lo0, strong = g >= a_hi0;
+      if (wraps) {  // u8 wrap of gradients >= 256: the bands of S whose low byte passes the thresholds
+        const bool w0 = g >= 262144u, w1 = g >= 1048576u;
+        cand = (cand && !w0) || (g >= p.a_lo[1] && !w1) || g >= p.a_lo[2];
+        strong = (strong && !w0) || (g >= p.a_hi[1] && !w1) || g >= p.a_hi[2];
+      }
+      const bool p1 = mul16<e, e>(A2, Um) > (int)g, p2 = mul16<e, e>(A2, Vp) > (int)g;
+      const u32 m0 = max(SN[1 + q], SU[1 + q]), m1 = max(SN[q], SU[2 + q]);
+      const u32 m2 = max(SC[2 + q], SC[q]), m3 = max(SU[q], SN[2 + q]);
+      const u32 mb = p1 ? (p2 ? m2 : m3) : (p2 ? m1 : m0);
+      const bool keep = mb <= g;
+      nibS |= (strong && keep) ? (1u << q) : 0u;
+      nibC |= (cand && keep) ? (1u << q) : 0u;
+    };
+    auto pr = [&](auto hc) {
+      constexpr int h = decltype(hc)::value;
+      const u32 X = v[18 + h], Y = v[20 + h];
+      const u32 A2 = R(U(X) + U(X)), Um = R(I(X) - I(Y)), Vp = R(U(X) + U(Y));
+      px(hc, std::integral_constant<int, 0>{}, A2, Um, Vp);
+      px(hc, std::integral_constant<int, 1>{}, A2, Um, Vp);
+    };
+    pr(std::integral_constant<int, 0>{});
+    pr(std::integral_constant<int, 1>{});
+    const u32 nib = nibS | (nibC << 8);
+    const u32 w = nib | (from_lane_above(nib) << 4);  // the partner's entry sits in the next lane
+    const u32 sl = v[22] & 63u, row = v[22] >> 8;
+    if (live && (sl & 1u)) {
+      const u32 o = row * plane_pitch + (u32)(strip * 31) + (sl >> 1);
+      splane[o] = (uint8_t)w;
+      cplane[o] = (uint8_t)(w >> 8);
+    }
+    if (p.prov_out && live && strip * STRIP_W - STRIP_HALO + 4 * (int)sl < W)
+      *reinterpret_cast<u32 *>(p.prov_out + (size_t)frame * p.prov_fs + (size_t)row * p.prov_pitch + (u32)(strip * STRIP_W) + 4u * (sl - 1u)) = nibble_to_bytes(nibS);
+    qhead += nent;
+    if (qhead >= NQ_CAP) qhead -= NQ_CAP;
+    qcount -= nent;
+  };
+
   // one step: blur row k arrives -> Sobel row k-1 -> NMS/threshold row k-2 (see k_front's phase 2)
   auto step = [&](auto uc, int k, u32 b) {
     constexpr int u = decltype(uc)::value;
@@ -896,10 +973,34 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
     const int c = k - 2;
     if (c >= r0 && c < rend) {
       u32 nib = 0;
+      bool queued = false;
       u64 cl[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) cl[q] = __ballot(Sr[sC][1 + q] >= a_lo0);
-      if ((cl[0] | cl[1] | cl[2] | cl[3]) != 0) {
+      const u64 any = (cl[0] | cl[1] | cl[2] | cl[3]) & 0x7FFFFFFFFFFFFFFEull;  // lanes 0 and 63 only carry halo columns
+      const u64 pm = any | ((any & 0x2AAAAAAAAAAAAAAAull) << 1) | ((any & 0x5555555555555554ull) >> 1);  // + partners
+      const int nadd = __builtin_popcountll(pm);
+      if (any != 0 && nadd <= NQ_INLINE) {
+        queued = __builtin_amdgcn_inverse_ballot_w64(pm);
+        if (queued) {
+          int idx = qhead + qcount + (int)mbcnt64(pm);
+          if (idx >= NQ_CAP) idx -= NQ_CAP;
+          u32 *ent = nq + idx * NQ_DW;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            ent[j] = Sr[sU][j];
+            ent[6 + j] = Sr[sC][j];
+            ent[12 + j] = Sr[sN][j];
+          }
+          ent[18] = Xr[rp][0];
+          ent[19] = Xr[rp][1];
+          ent[20] = Yr[rp][0];
+          ent[21] = Yr[rp][1];
+          ent[22] = ((u32)c << 8) | (u32)lane;
+        }
+        qcount += nadd;
+        if (qcount >= 64) nms_batch(64);
+      } else if (any != 0) {
         u64 st[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) st[q] = __ballot(Sr[sC][1 + q] >= a_hi0);
@@ -945,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
         pair(std::integral_constant<int, 0>{});
         nib = (nibS | (nibC << 8)) & oknib;
       }
-      if (p.prov_out && lane >= 1 && lane <= 62 && c0 < W) {  // provisional 0/255 map (strong bits); W % 4 == 0 here
+      if (p.prov_out && lane >= 1 && lane <= 62 && c0 < W && !queued) {  // provisional 0/255 map (strong bits); W % 4 == 0 here
         u32 po;
         asm("s_mul_i32 %0, %1, %2" : "=s"(po) : "s"(c), "s"(p.prov_pitch));
         u32 o = (u32)(strip * STRIP_W + 4 * (lane - 1));
@@ -953,7 +1054,7 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
         *reinterpret_cast<u32 *>(p.prov_out + (size_t)frame * p.prov_fs + po + o) = nibble_to_bytes(nib & 0xFu);
       }
       const u32 w = nib | (from_lane_above(nib) << 4);
-      if (store_lane) {
+      if (store_lane && !queued) {  // a queued pair's byte is stored by its batch
         u32 roff;
         asm("s_mul_i32 %0, %1, %2" : "=s"(roff) : "s"(c), "s"(plane_pitch));
         u32 so = st_off;
@@ -985,6 +1086,7 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
     step(std::integral_constant<int, 4>{}, k + 4, bc[4]);
     step(std::integral_constant<int, 5>{}, k + 5, bc[5]);
   }
+  if (qcount > 0) nms_batch(qcount);
 }
 
 template <int IN>
@@ -1004,7 +1106,7 @@ hipError_t launch_blur(const FrontParams &p, hipStream_t s)
 hipError_t launch_nms(const FrontParams &p, hipStream_t s)
 {
   if (p.run_rows_b < 1 || p.nchunks_b * p.run_rows_b < p.H || !p.blur) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_nms, dim3((p.total_items_b + 3) / 4), dim3(256), 0, s, p);
+  hipLaunchKernelGGL(k_nms, dim3((p.total_items_b + 3) / 4), dim3(256), (size_t)4 * NMS_WAVE_BYTES, s, p);
   return hipGetLastError();
 }
 
