@@ -126,11 +126,12 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    ctx.sync()                      # queues what the pipelined mode still holds back (the last step's hysteresis), waits
+                                    # for all of it and verifies the convergence of every step
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
-    ctx.sync()                      # also verifies hysteresis convergence of the last step
     ksums, kruns = ctx.profile_get_front()
     sums, nruns = ctx.profile_get(reset=True)
     work_launches, continued = ctx.hysteresis_info()

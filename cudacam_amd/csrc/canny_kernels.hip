@@ -809,7 +809,8 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
-  u32 *nq = reinterpret_cast<u32 *>(smem + wib * NMS_WAVE_BYTES);  // wave-private
+  typedef __attribute__((address_space(3))) u32 lds_u32;
+  lds_u32 *nq = (lds_u32 *)(smem + wib * NMS_WAVE_BYTES);  // wave-private
   const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
   if (item >= p.total_items_b) return;
   const int chunk = item % p.nchunks_b;
@@ -833,17 +834,24 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
   // own columns from this strip's segment; the halo lanes read the dword the neighbouring strip owns
   // (lane 0 <- strip-1 lane 62, lane 63 <- strip+1 lane 1); lanes without an image column read nothing (0)
   const uint8_t *bframe = p.blur + (size_t)frame * p.blur_frame_stride;  // wave-uniform
-  const int seg = lane == 0 ? strip - 1 : lane == 63 ? strip + 1 : strip;
-  const u32 bo = (u32)seg * (u32)H * 256u + (lane == 0 ? 248u : lane == 63 ? 4u : (u32)(4 * lane));
   const bool col_any = cmask != 0;  // false for lane 0 of strip 0 and for lanes right of the image (incl. a missing strip+1)
-  auto load_b = [&](int k) -> u32 {  // blur rows outside the image are 0 (zero padding, cannyEdgeD.cu:150-156)
-    u32 v = 0;
-    if (k >= 0 && k < H && col_any) {
-      u32 o = bo;
-      asm volatile("" : "+v"(o));
-      v = *reinterpret_cast<const u32 *>(bframe + (u32)k * 256u + o);
-    }
-    return v;
+  const int seg = !col_any ? strip : lane == 0 ? strip - 1 : lane == 63 ? strip + 1 : strip;
+  const u32 bo = (u32)seg * (u32)H * 256u + (!col_any ? (u32)(4 * lane) : lane == 0 ? 248u : lane == 63 ? 4u : (u32)(4 * lane));
+  const u32 lane_keep = col_any ? ~0u : 0u;
+  const int klast = min(H - 1, rend + 1);  // last blur row this run needs
+  // The loads are unconditional -- every lane reads a valid dword of the plane (rows clamped, lanes without an image
+  // column read their own strip's) and what must read as zero padding (cannyEdgeD.cu:150-156) is masked when the
+  // row is used.  An s_waitcnt for a conditional load could not count the loads issued after it and would drain
+  // the wave's stores as well.
+  auto load_b = [&](int k) -> u32 {
+    u32 o = bo;
+    asm volatile("" : "+v"(o));
+    return *reinterpret_cast<const u32 *>(bframe + (u32)min(max(k, 0), klast) * 256u + o);
+  };
+  auto use_b = [&](int k, u32 v) -> u32 {
+    u32 r = v & lane_keep;
+    if ((u32)k >= (u32)H) r = 0;  // wave-uniform
+    return r;
   };
 
   u32 dr[2][2], sr[2][2];  // d and s of the two previous blur rows, [ring][pair]
@@ -874,16 +882,25 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
   // once 64 entries wait, one dense pass does them, an entry per lane, and stores their bytes.  All other bytes
   // of a row are written as zeros straight away.  A row with many candidates (a horizontal edge) runs wave-wide.
   int qhead = 0, qcount = 0;  // wave-uniform; both even
+  // lanes that store a dword of the provisional map / a byte of the planes, and where row r0 starts (both advance by
+  // a pitch per output row: scalar adds instead of a multiply per row)
+  const u64 m_prov = uniform64(__ballot(lane >= 1 && lane <= 62 && c0 < W));
+  const u64 m_st = uniform64(__ballot(store_lane));
+  const u32 prov_voff = (u32)(strip * STRIP_W + 4 * (lane - 1));
+  u32 plane_roff = (u32)r0 * plane_pitch;
+  uint8_t *prov_row = p.prov_out ? p.prov_out + (size_t)frame * p.prov_fs + (size_t)r0 * p.prov_pitch : nullptr;
   auto nms_batch = [&](int nent) {
     wave_lds_sync();
     int idx = qhead + lane;
     if (idx >= NQ_CAP) idx -= NQ_CAP;
     const bool live = lane < nent;  // the other lanes compute on stale entries and store nothing
     u32 v[NQ_DW];
-    const uint4 *ent = reinterpret_cast<const uint4 *>(nq + idx * NQ_DW);
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+    const lds_u32x4 *ent = (const lds_u32x4 *)(nq + idx * NQ_DW);
 #pragma unroll
     for (int j = 0; j < NQ_DW / 4; ++j) {
-      const uint4 t = ent[j];
+      const u32x4 t = ent[j];
       v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
     }
     const u32 *SU = v, *SC = v + 6, *SN = v + 12;  // S rows above / at / below, [0] and [5] the neighbouring lanes' pixels
@@ -945,7 +962,7 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
     dk[1] = R(I(p3) - I(p1));
     sk[1] = pk_mad2(B, p1 + p3);
     const int i = k - 1;
-    const bool rowbad = i < 0 || i >= H;  // the Sobel rows just above / below the image are 0 (zero padding of every stage)
+    const bool rowbad = (u32)i >= (u32)H;  // the Sobel rows just above / below the image are 0 (zero padding of every stage)
     u32 Xv[2], Yv[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -971,36 +988,49 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
     for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
 
     const int c = k - 2;
-    if (c >= r0 && c < rend) {
-      u32 nib = 0;
-      bool queued = false;
+    if ((u32)(c - r0) < (u32)(rend - r0)) {
       u64 cl[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) cl[q] = __ballot(Sr[sC][1 + q] >= a_lo0);
       const u64 any = (cl[0] | cl[1] | cl[2] | cl[3]) & 0x7FFFFFFFFFFFFFFEull;  // lanes 0 and 63 only carry halo columns
       const u64 pm = any | ((any & 0x2AAAAAAAAAAAAAAAull) << 1) | ((any & 0x5555555555555554ull) >> 1);  // + partners
-      const int nadd = __builtin_popcountll(pm);
-      if (any != 0 && nadd <= NQ_INLINE) {
-        queued = __builtin_amdgcn_inverse_ballot_w64(pm);
-        if (queued) {
-          int idx = qhead + qcount + (int)mbcnt64(pm);
-          if (idx >= NQ_CAP) idx -= NQ_CAP;
-          u32 *ent = nq + idx * NQ_DW;
+      u32 nadd;  // as an instruction: the builtin's result is widened and the comparison below lands on the VALU
+      asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nadd) : "s"(pm) : "scc");
+      if (nadd <= (u32)NQ_INLINE) {
+        // the common case: few (or no) candidate lanes.  They go to the queue, every other byte of the row is zero.
+        if (any != 0) {
+          if (__builtin_amdgcn_inverse_ballot_w64(pm)) {
+            int idx = qhead + qcount + (int)mbcnt64(pm);
+            if (idx >= NQ_CAP) idx -= NQ_CAP;
+            lds_u32 *ent = nq + idx * NQ_DW;
 #pragma unroll
-          for (int j = 0; j < 6; ++j) {
-            ent[j] = Sr[sU][j];
-            ent[6 + j] = Sr[sC][j];
-            ent[12 + j] = Sr[sN][j];
+            for (int j = 0; j < 6; ++j) {
+              ent[j] = Sr[sU][j];
+              ent[6 + j] = Sr[sC][j];
+              ent[12 + j] = Sr[sN][j];
+            }
+            ent[18] = Xr[rp][0];
+            ent[19] = Xr[rp][1];
+            ent[20] = Yr[rp][0];
+            ent[21] = Yr[rp][1];
+            ent[22] = ((u32)c << 8) | (u32)lane;
           }
-          ent[18] = Xr[rp][0];
-          ent[19] = Xr[rp][1];
-          ent[20] = Yr[rp][0];
-          ent[21] = Yr[rp][1];
-          ent[22] = ((u32)c << 8) | (u32)lane;
+          qcount += (int)nadd;
         }
-        qcount += nadd;
+        if (p.prov_out && __builtin_amdgcn_inverse_ballot_w64(m_prov & ~pm)) {
+          u32 o = prov_voff;
+          asm volatile("" : "+v"(o));
+          *reinterpret_cast<u32 *>(prov_row + o) = 0u;
+        }
+        if (__builtin_amdgcn_inverse_ballot_w64(m_st & ~pm)) {  // a queued pair's byte is stored by its batch
+          u32 so = st_off;
+          asm volatile("" : "+v"(so));
+          (splane + plane_roff)[so] = 0;
+          (cplane + plane_roff)[so] = 0;
+        }
         if (qcount >= 64) nms_batch(64);
-      } else if (any != 0) {
+      } else {
+        // many candidates (a horizontal edge): the NMS on the whole wave
         u64 st[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) st[q] = __ballot(Sr[sC][1 + q] >= a_hi0);
@@ -1044,47 +1074,47 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
         };
         pair(std::integral_constant<int, 1>{});
         pair(std::integral_constant<int, 0>{});
-        nib = (nibS | (nibC << 8)) & oknib;
+        const u32 nib = (nibS | (nibC << 8)) & oknib;
+        if (p.prov_out && __builtin_amdgcn_inverse_ballot_w64(m_prov)) {  // provisional 0/255 map (strong bits); W % 4 == 0 here
+          u32 o = prov_voff;
+          asm volatile("" : "+v"(o));
+          *reinterpret_cast<u32 *>(prov_row + o) = nibble_to_bytes(nib & 0xFu);
+        }
+        const u32 w = nib | (from_lane_above(nib) << 4);
+        if (store_lane) {
+          u32 so = st_off;
+          asm volatile("" : "+v"(so));
+          (splane + plane_roff)[so] = (uint8_t)w;
+          (cplane + plane_roff)[so] = (uint8_t)(w >> 8);
+        }
       }
-      if (p.prov_out && lane >= 1 && lane <= 62 && c0 < W && !queued) {  // provisional 0/255 map (strong bits); W % 4 == 0 here
-        u32 po;
-        asm("s_mul_i32 %0, %1, %2" : "=s"(po) : "s"(c), "s"(p.prov_pitch));
-        u32 o = (u32)(strip * STRIP_W + 4 * (lane - 1));
-        asm volatile("" : "+v"(o));
-        *reinterpret_cast<u32 *>(p.prov_out + (size_t)frame * p.prov_fs + po + o) = nibble_to_bytes(nib & 0xFu);
-      }
-      const u32 w = nib | (from_lane_above(nib) << 4);
-      if (store_lane && !queued) {  // a queued pair's byte is stored by its batch
-        u32 roff;
-        asm("s_mul_i32 %0, %1, %2" : "=s"(roff) : "s"(c), "s"(plane_pitch));
-        u32 so = st_off;
-        asm volatile("" : "+v"(so));
-        (splane + roff)[so] = (uint8_t)w;
-        (cplane + roff)[so] = (uint8_t)(w >> 8);
-      }
+      plane_roff += plane_pitch;
+      prov_row += p.prov_pitch;
     }
   };
 
   // blur rows r0-2 .. rend+1, six per loop trip (the ring period); the next trip's six rows are requested
   // before this trip's are processed
   const int k0 = r0 - 2, kend = rend + 2;
+  // blur rows r0-2 .. rend+1, six steps per loop trip (the ring period).  Each row was requested six steps before it
+  // is used; its register is refilled at once, so a step only ever waits for the oldest of six loads in flight.
   u32 bn[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) bn[j] = load_b(k0 + j);
+  auto advance = [&](auto uc, int k) {
+    constexpr int j = decltype(uc)::value;
+    const u32 b = use_b(k, bn[j]);
+    bn[j] = load_b(k + 6);
+    step(uc, k, b);
+  };
 #pragma nounroll
   for (int k = k0; k < kend; k += 6) {
-    u32 bc[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) bc[j] = bn[j];
-    if (k + 6 < kend)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) bn[j] = load_b(k + 6 + j);
-    step(std::integral_constant<int, 0>{}, k + 0, bc[0]);
-    step(std::integral_constant<int, 1>{}, k + 1, bc[1]);
-    step(std::integral_constant<int, 2>{}, k + 2, bc[2]);
-    step(std::integral_constant<int, 3>{}, k + 3, bc[3]);
-    step(std::integral_constant<int, 4>{}, k + 4, bc[4]);
-    step(std::integral_constant<int, 5>{}, k + 5, bc[5]);
+    advance(std::integral_constant<int, 0>{}, k + 0);
+    advance(std::integral_constant<int, 1>{}, k + 1);
+    advance(std::integral_constant<int, 2>{}, k + 2);
+    advance(std::integral_constant<int, 3>{}, k + 3);
+    advance(std::integral_constant<int, 4>{}, k + 4);
+    advance(std::integral_constant<int, 5>{}, k + 5);
   }
   if (qcount > 0) nms_batch(qcount);
 }
@@ -1502,7 +1532,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   static_assert(NW == 1, "frames wider than one panel are tiled in column panels; a lane holds one dword per row");
   if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
   // latency-bound kernel (a few waves walking dependent row steps): when it shares a SIMD with the next
-  // run's k_front waves (pipelined mode) it should win the instruction arbitration
+  // run's front waves (pipelined mode) it should win the instruction arbitration
   __builtin_amdgcn_s_setprio(3);
   constexpr int ROWW = 64 * NW;  // dwords per row
   constexpr int BR = WAVES * TR;

@@ -3,7 +3,7 @@
 import csv, glob, sys
 f = sorted(glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True))[-1]
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_front" in r["Kernel_Name"]]
+idx = [i for i, r in enumerate(rows) if "k_front" in r["Kernel_Name"] or "k_blur" in r["Kernel_Name"]]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 t0 = int(rows[idx[-nsteps]]["Start_Timestamp"])
 for r in rows[idx[-nsteps]:]:
