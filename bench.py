@@ -34,8 +34,8 @@ HBM_MEASURED_COPY_GBPS = 6290.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100, help="timed steps (0.3 s of GPU time at the default batch; the pipelined mode exposes one hysteresis tail per run of steps)")
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU (2 GiB in + 2 GiB out at 1080p; hysteresis is latency-bound, larger batches amortise it)")
     ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
     ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
