@@ -1538,6 +1538,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   constexpr int BR = WAVES * TR;
   __shared__ u32 edge[(2 * WAVES + 2) * ROWW];  // per wave: first and last row of S; then the two halo rows
   __shared__ u32 bchg[24];
+  constexpr int XQ_CAP = 256;  // a row adds up to 128 groups to a queue holding fewer than 64
+  __shared__ u32 xqueue[WAVES * XQ_CAP];
   const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // tiles are 2-D: row tile bt x column panel pn (a panel = ROWW dwords = 2048 columns; frames up to 2048
   // columns have one panel).  A wave always holds one dword per lane and row, whatever the frame width.
@@ -1718,7 +1720,20 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       if (r == 0) publish(my_first, 0);
       if (r == n - 1) publish(my_last, n - 1);
       round_changed |= 1ull << r;
-      dirty |= ((1ull << r) >> 1) | (((1ull << r) << 1) & all_rows);
+      // The row below is looked at again in any case.  The row above only if a new bit reaches one of its open
+      // candidates: it is at its own fixpoint for everything but this change (in a downward sweep nearly every step
+      // used to be followed by a second look at the row above that found nothing).
+      dirty |= ((1ull << r) << 1) & all_rows;
+      if (r > 0) {
+        RowBits<NW> nb;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) nb.w[j] = f.w[j] & ~s.w[j];
+        const RowBits<NW> reach = row_dilate<NW>(nb);
+        bool hit = false;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) hit = hit || (reach.w[j] & cr[j][r - 1] & ~sr[j][r - 1]) != 0;
+        if (__ballot(hit) != 0) dirty |= (1ull << r) >> 1;
+      }
     }
     changed |= round_changed;
     if (lane == 0) bchg[wib] = (n > 0 && (round_changed & 1ull) ? 1u : 0u) | (n > 0 && ((round_changed >> (n - 1)) & 1ull) ? 2u : 0u);
@@ -1740,51 +1755,95 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   // cannyEdgeD.cu:379-395: strong bits -> 255, rest 0; 16 px per lane per store).  When the output already shows
   // the planes as they were in memory -- k_nms wrote the strong pixels (p.prov), or an earlier launch left it so --
   // only the 16-pixel groups whose bits changed are rewritten: the old dword of a row is read back (one row ahead)
-  // and compared before the new one is stored.
+  // and compared with the new one.  A changed row typically has two or three such groups out of 120, so they are not
+  // expanded row by row (a few active lanes per instruction) but collected in a wave-private LDS queue -- one dword
+  // per group: its 16 bits, row and position -- and expanded 64 at a time, a group per lane.
   {
     const bool patch = p.out && (p.iter > 0 || p.prov);
     const bool a16 = (((uintptr_t)p.out | p.out_pitch | p.out_frame_stride) & 15u) == 0;
     uint8_t *obase = p.out ? p.out + (size_t)frame * p.out_frame_stride : nullptr;
     const bool in_panel = pcol + lane < RD;
-    u32 *Srow = S + (size_t)(b0 + w0) * RD + pcol + lane;  // this lane's dword of the wave's first row
-    u64 m = (p.out && !patch) ? all_rows : changed;
-    u32 oldn = 0;
-    if (patch && m && in_panel) oldn = Srow[(size_t)__builtin_ctzll(m) * RD];
-    while (m) {
-      const int r = __builtin_ctzll(m);
-      m &= m - 1;
-      const u32 old = oldn;
-      if (patch && m && in_panel) oldn = Srow[(size_t)__builtin_ctzll(m) * RD];
-      const u32 rowv = sr[0][r];
-      u64 mlo = ~0ull, mhi = ~0ull;  // which half-words (16-pixel groups) of the row changed: bit L = dword L
-      if (patch) {
-        const u32 dv = old ^ rowv;
-        mlo = __ballot((dv & 0xFFFFu) != 0);
-        mhi = __ballot((dv >> 16) != 0);
+    u32 *Sw = S + (size_t)(b0 + w0) * RD;  // the wave's first row (uniform); this lane's dword is at pcol + lane
+    const u32 s_lane = (u32)(pcol + lane);
+    // 16 pixels whose bits are `b`, starting at column c0 of row `row` of this frame
+    auto put16 = [&](u32 b, int row, int c0) {
+      if (c0 >= p.W) return;
+      u32 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
+      uint8_t *dst = obase + (size_t)row * p.out_pitch + c0;
+      if (c0 + 15 < p.W) {
+        if (a16) *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+        else
+#pragma unroll
+          for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
+      } else {
+        for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
       }
-      if (((changed >> r) & 1ull) && in_panel) Srow[(size_t)r * RD] = rowv;
-      if (!p.out) continue;
-      uint8_t *orow = obase + (size_t)(b0 + w0 + r) * p.out_pitch;
-      for (int pass = 0; pass * 1024 < ROWW * 32 && pcol * 32 + pass * 1024 < p.W; ++pass) {
-        // this lane writes px [32*pcol + 1024*pass + 16*lane, +16): half-word 64*pass + lane of the panel row
-        const int D = 32 * pass + (lane >> 1);  // dword (of the panel) holding it
-        const u32 x = __shfl(rowv, D);  // before any lane drops out: the permute only sees the values of active lanes
-        if (patch && ((((lane & 1) ? mhi : mlo) >> D) & 1ull) == 0) continue;  // this group of 16 pixels did not change
-        const u32 b = (x >> (16 * (lane & 1))) & 0xFFFFu;
-        const int c0 = pcol * 32 + pass * 1024 + lane * 16;
-        if (c0 >= p.W) continue;
-        u32 v[4];
+    };
+    u32 *xq = xqueue + wib * XQ_CAP;  // ring of changed groups: bits | row << 16 | group-of-the-panel-row << 21
+    int xhead = 0, xcount = 0;
+    auto xflush = [&](int nent) {
+      wave_lds_sync();
+      const u32 ent = xq[(xhead + lane) & (XQ_CAP - 1)];
+      if (lane < nent) put16(ent & 0xFFFFu, b0 + w0 + (int)((ent >> 16) & 31u), pcol * 32 + (int)(ent >> 21) * 16);
+      xhead = (xhead + nent) & (XQ_CAP - 1);
+      xcount -= nent;
+    };
+    if (p.out && !patch) {
+      // first launch on planes the output does not show yet: every row of the tile, whole rows, two passes of 64 groups
+      for (int r = 0; r < n; ++r) {
+        const u32 rowv = sr[0][r];
+        if (((changed >> r) & 1ull) && in_panel) (Sw + (size_t)r * RD)[s_lane] = rowv;
+        uint8_t *orow = obase + (size_t)(b0 + w0 + r) * p.out_pitch;
+        for (int pass = 0; pass * 1024 < ROWW * 32 && pcol * 32 + pass * 1024 < p.W; ++pass) {
+          // this lane writes px [32*pcol + 1024*pass + 16*lane, +16): half-word 64*pass + lane of the panel row
+          const u32 x = __shfl(rowv, 32 * pass + (lane >> 1));  // before any lane drops out: the permute only sees active lanes
+          const u32 b = (x >> (16 * (lane & 1))) & 0xFFFFu;
+          const int c0 = pcol * 32 + pass * 1024 + lane * 16;
+          if (c0 >= p.W) continue;
+          u32 v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
-        uint8_t *dst = orow + c0;
-        if (c0 + 15 < p.W) {
-          if (a16) *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
-          else
+          for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
+          uint8_t *dst = orow + c0;
+          if (c0 + 15 < p.W) {
+            if (a16) *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
+            else
 #pragma unroll
-            for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
-        } else {
-          for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+              for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
+          } else {
+            for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+          }
         }
+      }
+    } else {
+      u64 m = changed;
+      u32 oldn = 0;
+      if (patch && m && in_panel) oldn = (Sw + (size_t)__builtin_ctzll(m) * RD)[s_lane];
+      for (;;) {
+        if (xcount >= 64 || (m == 0 && xcount > 0)) {  // the one place where groups are expanded
+          xflush(min(xcount, 64));
+          continue;
+        }
+        if (m == 0) break;
+        const int r = __builtin_ctzll(m);
+        m &= m - 1;
+        const u32 old = oldn;
+        if (patch && m && in_panel) oldn = (Sw + (size_t)__builtin_ctzll(m) * RD)[s_lane];
+        const u32 rowv = sr[0][r];
+        if (in_panel) (Sw + (size_t)r * RD)[s_lane] = rowv;
+        if (!patch) continue;  // no output at all (hc_hysteresis_device on planes only)
+        const u32 dv = old ^ rowv;
+        const bool clo = (dv & 0xFFFFu) != 0, chi = (dv >> 16) != 0;
+        const u64 mlo = __ballot(clo), mhi = __ballot(chi);
+        if ((mlo | mhi) == 0) continue;
+        u32 nlo, nhi;
+        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nlo) : "s"(mlo) : "scc");
+        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nhi) : "s"(mhi) : "scc");
+        const u32 base = (u32)(xhead + xcount), tag = (u32)r << 16;
+        if (clo) xq[(base + mbcnt64(mlo)) & (XQ_CAP - 1)] = (rowv & 0xFFFFu) | tag | ((u32)(2 * lane) << 21);
+        if (chi) xq[(base + nlo + mbcnt64(mhi)) & (XQ_CAP - 1)] = (rowv >> 16) | tag | ((u32)(2 * lane + 1) << 21);
+        xcount += (int)(nlo + nhi);
       }
     }
   }
