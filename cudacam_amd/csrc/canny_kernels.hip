@@ -1526,10 +1526,13 @@ void hyst_tile_geometry(int RD, bool beside_front, int *tile_rows, int *waves)
   *waves = g.waves;
 }
 
-template <int NW, int TR, int WAVES>
+// PANELS: the frame is wider than one 2048-column panel (tiles then also have left / right neighbours); the common
+// narrower case is compiled without that code
+template <int NW, int TR, int WAVES, bool PANELS>
 __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 {
   static_assert(NW == 1, "frames wider than one panel are tiled in column panels; a lane holds one dword per row");
+  static_assert((TR & (TR - 1)) == 0, "row indices are wrapped with TR - 1");
   if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
   // latency-bound kernel (a few waves walking dependent row steps): when it shares a SIMD with the next
   // run's front waves (pipelined mode) it should win the instruction arbitration
@@ -1543,7 +1546,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // tiles are 2-D: row tile bt x column panel pn (a panel = ROWW dwords = 2048 columns; frames up to 2048
   // columns have one panel).  A wave always holds one dword per lane and row, whatever the frame width.
-  const int NP = p.npanels, ntile = p.nrtiles * NP;
+  const int NP = PANELS ? p.npanels : 1, ntile = p.nrtiles * NP;
   const int tile = blockIdx.x % ntile, frame = blockIdx.x / ntile;
   const int bt = tile / NP, pn = tile % NP;
   const int H = p.H, RD = p.RD;
@@ -1566,7 +1569,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
     // A neighbour's boundary row changed somewhere -- but does a new bit reach a candidate of this tile?  Only
     // then can anything change here (the tile is at its own fixpoint).  Checked on the two boundary rows alone
     // (4 row loads) before the 2 x TR rows per wave are fetched: most tiles leave here in launches >= 1.
-    if (!side && NP == 1) {
+    if (!PANELS && !side) {
       u32 *S0 = p.sbits + (size_t)frame * H * RD;
       const u32 *C0 = p.cbits + (size_t)frame * H * RD;
       bool hit = false;
@@ -1608,14 +1611,27 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   //  plain arrays with dynamic stores would be demoted to scratch)
   typedef u32 RowVec __attribute__((ext_vector_type(TR)));
   RowVec cr[NW], sr[NW];
+  // (a panel is always 64 whole dwords wide -- launch_hyst: RD % 64 == 0 -- so only the row count limits the loads)
+  if (n == TR) {  // all but the last wave tile of a frame: no per-row test
 #pragma unroll
-  for (int i = 0; i < TR; ++i) {
+    for (int i = 0; i < TR; ++i) {
 #pragma unroll
-    for (int j = 0; j < NW; ++j) {
-      const bool ok = i < n && pcol + lane * NW + j < RD;
-      const size_t off = (size_t)(b0 + w0 + i) * RD + pcol + lane * NW + j;
-      cr[j][i] = ok ? C[off] : 0u;
-      sr[j][i] = ok ? S[off] : 0u;
+      for (int j = 0; j < NW; ++j) {
+        const size_t off = (size_t)(b0 + w0 + i) * RD + pcol + lane * NW + j;
+        cr[j][i] = C[off];
+        sr[j][i] = S[off];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TR; ++i) {
+#pragma unroll
+      for (int j = 0; j < NW; ++j) {
+        const bool ok = i < n;  // wave-uniform
+        const size_t off = (size_t)(b0 + w0 + i) * RD + pcol + lane * NW + j;
+        cr[j][i] = ok ? C[off] : 0u;
+        sr[j][i] = ok ? S[off] : 0u;
+      }
     }
   }
   u32 *my_first = edge + (2 * wib) * ROWW, *my_last = edge + (2 * wib + 1) * ROWW;
@@ -1652,7 +1668,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   // rows and the row above / below them -- bit k of the mask = row w0 - 1 + k.  Like the row halos they belong to
   // other workgroups and are as of the start of this launch.
   u64 lmask = 0, rmask = 0;
-  if (NP > 1 && n > 0) {
+  if (PANELS && n > 0) {
     const int hr = b0 + w0 - 1 + lane;  // lanes 0 .. n+1 fetch one row each
     const bool rok = lane < n + 2 && hr >= 0 && hr < H;
     const u32 lv = (rok && pn > 0) ? S[(size_t)hr * RD + pcol - 1] : 0u;
@@ -1678,8 +1694,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       RowBits<NW> up, dn, s, c;
 #pragma unroll
       for (int j = 0; j < NW; ++j) {
-        up.w[j] = r == 0 ? up_src[lane * NW + j] : sr[j][r > 0 ? r - 1 : 0];
-        dn.w[j] = r == n - 1 ? dn_src[lane * NW + j] : sr[j][r + 1 < TR ? r + 1 : r];
+        // (index wrapped instead of clamped -- TR is a power of two -- the wrapped row is never the one used)
+        up.w[j] = r == 0 ? up_src[lane * NW + j] : sr[j][(r - 1) & (TR - 1)];
+        dn.w[j] = r == n - 1 ? dn_src[lane * NW + j] : sr[j][(r + 1) & (TR - 1)];
         s.w[j] = sr[j][r];
         c.w[j] = cr[j][r];
       }
@@ -1687,7 +1704,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 #pragma unroll
       for (int j = 0; j < NW; ++j) nbr.w[j] = up.w[j] | dn.w[j];
       RowBits<NW> d = row_dilate<NW>(nbr);
-      if (NP > 1) {  // a strong pixel in the column next to the panel, rows r-1 .. r+1, touches my first / last column
+      if (PANELS) {  // a strong pixel in the column next to the panel, rows r-1 .. r+1, touches my first / last column
         if (((lmask >> r) & 7ull) != 0 && lane == 0) d.w[0] |= 1u;
         if (((rmask >> r) & 7ull) != 0 && lane == 63) d.w[NW - 1] |= 0x80000000u;
       }
@@ -1711,7 +1728,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 #pragma unroll
       for (int j = 0; j < NW; ++j) ch = ch || (f.w[j] != s.w[j]);
       if (__ballot(ch) == 0) continue;
-      if (NP > 1) {  // did the panel's first / last column change? (lane 0 bit 0, lane 63 bit 31)
+      if (PANELS) {  // did the panel's first / last column change? (lane 0 bit 0, lane 63 bit 31)
         const u32 x0 = f.w[0] ^ s.w[0], x1 = f.w[NW - 1] ^ s.w[NW - 1];
         colchg |= (u32)(__builtin_amdgcn_readlane((int)x0, 0) & 1) | (((u32)__builtin_amdgcn_readlane((int)x1, 63) >> 31) << 1);
       }
@@ -1762,7 +1779,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
     const bool patch = p.out && (p.iter > 0 || p.prov);
     const bool a16 = (((uintptr_t)p.out | p.out_pitch | p.out_frame_stride) & 15u) == 0;
     uint8_t *obase = p.out ? p.out + (size_t)frame * p.out_frame_stride : nullptr;
-    const bool in_panel = pcol + lane < RD;
     u32 *Sw = S + (size_t)(b0 + w0) * RD;  // the wave's first row (uniform); this lane's dword is at pcol + lane
     const u32 s_lane = (u32)(pcol + lane);
     // 16 pixels whose bits are `b`, starting at column c0 of row `row` of this frame
@@ -1794,7 +1810,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       // first launch on planes the output does not show yet: every row of the tile, whole rows, two passes of 64 groups
       for (int r = 0; r < n; ++r) {
         const u32 rowv = sr[0][r];
-        if (((changed >> r) & 1ull) && in_panel) (Sw + (size_t)r * RD)[s_lane] = rowv;
+        if ((changed >> r) & 1ull) (Sw + (size_t)r * RD)[s_lane] = rowv;
         uint8_t *orow = obase + (size_t)(b0 + w0 + r) * p.out_pitch;
         for (int pass = 0; pass * 1024 < ROWW * 32 && pcol * 32 + pass * 1024 < p.W; ++pass) {
           // this lane writes px [32*pcol + 1024*pass + 16*lane, +16): half-word 64*pass + lane of the panel row
@@ -1819,7 +1835,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
     } else {
       u64 m = changed;
       u32 oldn = 0;
-      if (patch && m && in_panel) oldn = (Sw + (size_t)__builtin_ctzll(m) * RD)[s_lane];
+      if (patch && m) oldn = (Sw + (size_t)__builtin_ctzll(m) * RD)[s_lane];
       for (;;) {
         if (xcount >= 64 || (m == 0 && xcount > 0)) {  // the one place where groups are expanded
           xflush(min(xcount, 64));
@@ -1829,9 +1845,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
         const int r = __builtin_ctzll(m);
         m &= m - 1;
         const u32 old = oldn;
-        if (patch && m && in_panel) oldn = (Sw + (size_t)__builtin_ctzll(m) * RD)[s_lane];
+        if (patch && m) oldn = (Sw + (size_t)__builtin_ctzll(m) * RD)[s_lane];
         const u32 rowv = sr[0][r];
-        if (in_panel) (Sw + (size_t)r * RD)[s_lane] = rowv;
+        (Sw + (size_t)r * RD)[s_lane] = rowv;
         if (!patch) continue;  // no output at all (hc_hysteresis_device on planes only)
         const u32 dv = old ^ rowv;
         const bool clo = (dv & 0xFFFFu) != 0, chi = (dv >> 16) != 0;
@@ -1870,11 +1886,18 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   if (p.RD > 256) return hipErrorInvalidValue;
   if (p.npanels != (p.RD + 63) / 64 || p.RD % 64) return hipErrorInvalidValue;
   const dim3 grid((unsigned)(p.nframes * p.nrtiles * p.npanels)), block(64 * g.waves);
-  if (g.nw == 1 && g.tr == 32 && g.waves == 8) hipLaunchKernelGGL((k_hyst<1, 32, 8>), grid, block, 0, s, p);
-  else if (g.nw == 1 && g.tr == 32 && g.waves == 4) hipLaunchKernelGGL((k_hyst<1, 32, 4>), grid, block, 0, s, p);
-  else if (g.nw == 1 && g.tr == 32 && g.waves == 2) hipLaunchKernelGGL((k_hyst<1, 32, 2>), grid, block, 0, s, p);
-  else if (g.nw == 1 && g.tr == 16 && g.waves == 8) hipLaunchKernelGGL((k_hyst<1, 16, 8>), grid, block, 0, s, p);
-  else if (g.nw == 1 && g.tr == 32 && g.waves == 16) hipLaunchKernelGGL((k_hyst<1, 32, 16>), grid, block, 0, s, p);
+  const bool wide = p.npanels > 1;
+#define HC_HYST_LAUNCH(TR_, WAVES_)                                                         \
+  {                                                                                          \
+    if (wide) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true>), grid, block, 0, s, p);      \
+    else hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, false>), grid, block, 0, s, p);          \
+  }
+  if (g.nw == 1 && g.tr == 32 && g.waves == 8) HC_HYST_LAUNCH(32, 8)
+  else if (g.nw == 1 && g.tr == 32 && g.waves == 4) HC_HYST_LAUNCH(32, 4)
+  else if (g.nw == 1 && g.tr == 32 && g.waves == 2) HC_HYST_LAUNCH(32, 2)
+  else if (g.nw == 1 && g.tr == 16 && g.waves == 8) HC_HYST_LAUNCH(16, 8)
+  else if (g.nw == 1 && g.tr == 32 && g.waves == 16) HC_HYST_LAUNCH(32, 16)
+#undef HC_HYST_LAUNCH
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }
