@@ -68,6 +68,50 @@ def test_chunk_invariance(oracle, chunk, split):
         _diff(ctx.process(img)[0], want, f"chunk {chunk} split {split}")
 
 
+def _nms_queue_patterns():
+    """Frames that steer k_nms through each of its paths: a few candidate lanes per wave-row (queued), many (wave-wide),
+    candidates in the first / last lanes of a strip and in both lanes of an output byte, batches that fill exactly and
+    entries left over at the end of a run."""
+    rng = np.random.default_rng(11)
+    w, h = 1000, 150                                     # 5 strips of 248 columns, the last one ragged
+    a = np.full((h, w), 60, np.uint8)
+    for x in (3, 247, 248, 249, 251, 252, 495, 496, 500, 743, 744, 991, 999):   # thin vertical lines at strip borders and lane pairs
+        a[:, x] = 200
+    yield "vertical_lines", a
+    b = np.full((h, w), 60, np.uint8)
+    b[40:43, :] = 220                                    # horizontal edges: every lane of the row has candidates
+    b[90, 100:140] = 220                                 # a short one: about ten lanes
+    b[120, 300:368] = 220                                # 17 lanes: just above the wave-wide threshold in one strip, below in the next
+    yield "horizontal_lines", b
+    c = np.full((h, w), 30, np.uint8)
+    ys = rng.integers(3, h - 3, 400); xs = rng.integers(3, w - 3, 400)
+    c[ys, xs] = 255                                      # isolated dots: one or two lanes per row, many rows
+    yield "dots", c
+    d = np.full((67, 300), 20, np.uint8)                 # one run that ends with a partly filled queue
+    d[5:60, 150] = 250
+    yield "short_run", d
+    e = np.full((h, w), 90, np.uint8)
+    for k in range(-h, w, 37):                           # diagonals: a candidate lane that moves by one column per row
+        for y in range(h):
+            if 0 <= k + y < w:
+                e[y, k + y] = 230
+    yield "diagonals", e
+
+
+@pytest.mark.parametrize("name,img", list(_nms_queue_patterns()), ids=[n for n, _ in _nms_queue_patterns()])
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_nms_queue_paths(oracle, name, img, pipeline):
+    h, w = img.shape
+    for low, high in ((10, 40), (60, 200)):
+        want = oracle.canny_r(img, low, high)
+        with api.Context(w, h, 1, 2) as ctx:
+            ctx.set_thresholds(low, high)
+            ctx.set_option(api.OPT_PIPELINE, pipeline)
+            got = ctx.process(np.stack([img, img[::-1].copy()]), api.CannyStage.HYSTER)
+            _diff(got[0], want, f"{name} {low}/{high} pipeline={pipeline}")
+            _diff(got[1], oracle.canny_r(img[::-1].copy(), low, high), f"{name} flipped {low}/{high} pipeline={pipeline}")
+
+
 @pytest.mark.parametrize("kind", ["noise", "flat", "steps", "natural"])
 def test_fused_front_kernel(oracle, kind):
     """HC_OPT_FRONT_SPLIT = 0: the single fused kernel (no blur plane) gives the same maps, BGR included."""
