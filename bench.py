@@ -177,14 +177,16 @@ def main():
         }
         # HBM bytes per launch of the front kernels from the committed PMC passes (separate rocprofv3 runs of this
         # command, tools/collect_profiles.sh); only quoted when that profile was taken on this very configuration
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
-            if prof["config"] == out["config"] and prof["metric"] == out["metric"]:
-                out["roofline"]["traffic"] = round(prof["front_kernels_hbm_bytes_per_launch"] / 1e9, 3)
-                out["roofline"]["traffic_unit"] = "GB per launch (2*FETCH_SIZE + WRITE_SIZE, profiles/r01/pmc_traffic.json)"
-                out["roofline"]["algorithmic_GB_per_launch"] = round(alg_bytes_per_launch / 1e9, 3)
-        except (OSError, KeyError, ValueError):
-            pass
+        import glob
+        for pf in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic.json"))):
+            try:
+                prof = json.load(open(pf))
+                if prof["config"] == out["config"] and prof["metric"] == out["metric"]:
+                    out["roofline"]["traffic"] = round(prof["front_kernels_hbm_bytes_per_launch"] / 1e9, 3)
+                    out["roofline"]["traffic_unit"] = "GB per launch (2*FETCH_SIZE + WRITE_SIZE, " + os.path.relpath(pf, ROOT) + ")"
+                    out["roofline"]["algorithmic_GB_per_launch"] = round(alg_bytes_per_launch / 1e9, 3)
+            except (OSError, KeyError, ValueError):
+                pass
         if not a.no_cpu_baseline and C == 1:
             out["cpu_baseline"] = cpu_baseline(a, d_in, d_out)
         print(json.dumps(out), flush=True)
