@@ -747,20 +747,41 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
       accumulate(xw[j], Sp);
     }
   }
+  // Plain u8 input: the loads are unconditional (rows clamped to what the run needs, lanes without an image column
+  // read the row's first dword; both are masked when the row is used), each row's register is refilled as soon as it
+  // has been consumed, and a row then waits for the oldest of G loads in flight (vmcnt(G-1)) -- with conditional loads
+  // the compiler can only wait for everything, the wave's stores included (see k_nms).
+  const int rlast = min(H - 1, rend + 1);  // last input row this run needs
+  const u32 ld_safe = col_any ? ld_off : 0u;
+  auto load_raw = [&](int row) -> u32 {
+    u32 lo = ld_safe;
+    asm volatile("" : "+v"(lo));
+    return *reinterpret_cast<const u32 *>(frame_base + (u32)min(max(row, 0), rlast) * in_pitch32 + lo);
+  };
   u32 xn[G];
 #pragma unroll
-  for (int j = 0; j < G; ++j) xn[j] = load_row(r0 + 2 + j);
+  for (int j = 0; j < G; ++j) xn[j] = IN == 0 ? load_raw(r0 + 2 + j) : load_row(r0 + 2 + j);
   int wb0 = r0;  // first blur row of the current fix-up window
 #pragma nounroll
   for (int rb0 = r0; rb0 < rend; rb0 += G) {
-    u32 xc[G];
+    if (IN == 0) {
 #pragma unroll
-    for (int j = 0; j < G; ++j) xc[j] = xn[j];
-    if (rb0 + G < rend)
+      for (int j = 0; j < G; ++j) {
+        u32 x = xn[j];
+        if ((u32)(rb0 + 2 + j) >= (u32)H) x = 0;  // wave-uniform: zero padding below the image (above it: the warm-up rows)
+        xn[j] = load_raw(rb0 + 2 + G + j);
+        blur_row(rb0 + j, rb0 - wb0 + j, x);
+      }
+    } else {
+      u32 xc[G];
 #pragma unroll
-      for (int j = 0; j < G; ++j) xn[j] = load_row(rb0 + 2 + G + j);
+      for (int j = 0; j < G; ++j) xc[j] = xn[j];
+      if (rb0 + G < rend)
 #pragma unroll
-    for (int j = 0; j < G; ++j) blur_row(rb0 + j, rb0 - wb0 + j, xc[j]);
+        for (int j = 0; j < G; ++j) xn[j] = load_row(rb0 + 2 + G + j);
+#pragma unroll
+      for (int j = 0; j < G; ++j) blur_row(rb0 + j, rb0 - wb0 + j, xc[j]);
+    }
     if (rb0 + G - wb0 < BSUB && rb0 + G < rend) continue;
     // fix-up of the window [wb0, rb0 + G): the queued pixels get the literal chain, written over the plane
     // bytes (same wave, program order).  Queue overflow (flat areas): every pixel of the window is recomputed.
