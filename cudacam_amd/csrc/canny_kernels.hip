@@ -1203,14 +1203,18 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
   const uint8_t *fbase = p.in + (size_t)frame * p.in_frame_stride;  // wave-uniform
   const u32 in_pitch32 = (u32)p.in_pitch;                            // launch_front_o checks H * pitch < 2^32
   const u32 ld_off = (u32)ld_col;
-  auto load_row = [&](int row) -> u32 {  // BORDER_REPLICATE along the column: clamp the row
-    const int rr = min(max(row, 0), H - 1);
+  const int rlast = min(H - 1, rend + 1);  // last source row this run needs
+  auto load_row = [&](int row) -> u32 {  // BORDER_REPLICATE along the column: clamp the row; the raw dword (see use_row)
+    const int rr = min(max(row, 0), rlast);
     u32 roff;
     asm("s_mul_i32 %0, %1, %2" : "=s"(roff) : "s"(rr), "s"(in_pitch32));
     u32 o = ld_off;
     asm volatile("" : "+v"(o));  // scalar row base + 32-bit lane offset
-    return __builtin_amdgcn_perm(0u, *reinterpret_cast<const u32 *>(fbase + roff + o), rsel);
+    return *reinterpret_cast<const u32 *>(fbase + roff + o);
   };
+  // BORDER_REPLICATE along the row: the byte selector, applied when the row is consumed -- applied at the load it
+  // made the wave wait for each request at once
+  auto use_row = [&](u32 raw) -> u32 { return __builtin_amdgcn_perm(0u, raw, rsel); };
 
   u32 dr[2][2], sr[2][2];  // d = x[+1]-x[-1] and s = x[-1]+2x[0]+x[+1] of the two previous rows, [ring][pair]
   u32 Mr[3][6];            // magnitude rows: [ring][0]=left neighbour, [1..4]=own 4 px, [5]=right neighbour
@@ -1336,25 +1340,26 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
     }
   };
 
-  // source rows r0-2 .. rend+1, six per loop trip (the ring period); the next trip's rows are requested first
+  // source rows r0-2 .. rend+1, six steps per loop trip (the ring period); a row is requested six steps before it is
+  // used and its register refilled at once (unconditional loads: a step waits for the oldest of six, see k_nms)
   const int k0 = r0 - 2, kend = rend + 2;
   u32 bn[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) bn[j] = load_row(k0 + j);
+  auto advance = [&](auto uc, int k) {
+    constexpr int j = decltype(uc)::value;
+    const u32 b = use_row(bn[j]);
+    bn[j] = load_row(k + 6);
+    step(uc, k, b);
+  };
 #pragma nounroll
   for (int k = k0; k < kend; k += 6) {
-    u32 bc[6];
-#pragma unroll
-    for (int j = 0; j < 6; ++j) bc[j] = bn[j];
-    if (k + 6 < kend)
-#pragma unroll
-      for (int j = 0; j < 6; ++j) bn[j] = load_row(k + 6 + j);
-    step(std::integral_constant<int, 0>{}, k + 0, bc[0]);
-    step(std::integral_constant<int, 1>{}, k + 1, bc[1]);
-    step(std::integral_constant<int, 2>{}, k + 2, bc[2]);
-    step(std::integral_constant<int, 3>{}, k + 3, bc[3]);
-    step(std::integral_constant<int, 4>{}, k + 4, bc[4]);
-    step(std::integral_constant<int, 5>{}, k + 5, bc[5]);
+    advance(std::integral_constant<int, 0>{}, k + 0);
+    advance(std::integral_constant<int, 1>{}, k + 1);
+    advance(std::integral_constant<int, 2>{}, k + 2);
+    advance(std::integral_constant<int, 3>{}, k + 3);
+    advance(std::integral_constant<int, 4>{}, k + 4);
+    advance(std::integral_constant<int, 5>{}, k + 5);
   }
 }
 
