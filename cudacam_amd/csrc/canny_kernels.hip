@@ -1860,32 +1860,47 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       }
     } else {
       u64 m = changed;
-      u32 oldn = 0;
-      if (patch && m) oldn = (Sw + (size_t)__builtin_ctzll(m) * RD)[s_lane];
+      typedef u32 Old16 __attribute__((ext_vector_type(16)));
       for (;;) {
         if (xcount >= 64 || (m == 0 && xcount > 0)) {  // the one place where groups are expanded
           xflush(min(xcount, 64));
           continue;
         }
         if (m == 0) break;
-        const int r = __builtin_ctzll(m);
-        m &= m - 1;
-        const u32 old = oldn;
-        if (patch && m) oldn = (Sw + (size_t)__builtin_ctzll(m) * RD)[s_lane];
-        const u32 rowv = sr[0][r];
-        (Sw + (size_t)r * RD)[s_lane] = rowv;
-        if (!patch) continue;  // no output at all (hc_hysteresis_device on planes only)
-        const u32 dv = old ^ rowv;
-        const bool clo = (dv & 0xFFFFu) != 0, chi = (dv >> 16) != 0;
-        const u64 mlo = __ballot(clo), mhi = __ballot(chi);
-        if ((mlo | mhi) == 0) continue;
-        u32 nlo, nhi;
-        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nlo) : "s"(mlo) : "scc");
-        asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nhi) : "s"(mhi) : "scc");
-        const u32 base = (u32)(xhead + xcount), tag = (u32)r << 16;
-        if (clo) xq[(base + mbcnt64(mlo)) & (XQ_CAP - 1)] = (rowv & 0xFFFFu) | tag | ((u32)(2 * lane) << 21);
-        if (chi) xq[(base + nlo + mbcnt64(mhi)) & (XQ_CAP - 1)] = (rowv >> 16) | tag | ((u32)(2 * lane + 1) << 21);
-        xcount += (int)(nlo + nhi);
+        // What the plane (and with it the output) showed before this launch, for the next up to 16 changed rows: all
+        // requests at once, one wait.  (Read back one row ahead inside the loop, each changed row waited for its own
+        // load and -- the load being conditional -- for the stores before it as well.)
+        Old16 oldv;
+        if (patch) {
+          u64 mb = m;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            u32 v = 0;
+            if (mb) {
+              v = (Sw + (size_t)__builtin_ctzll(mb) * RD)[s_lane];
+              mb &= mb - 1;
+            }
+            oldv[j] = v;
+          }
+        }
+        for (int j = 0; j < 16 && m != 0 && xcount < 64; ++j) {
+          const int r = __builtin_ctzll(m);
+          m &= m - 1;
+          const u32 rowv = sr[0][r];
+          (Sw + (size_t)r * RD)[s_lane] = rowv;
+          if (!patch) continue;  // no output at all (hc_hysteresis_device on planes only)
+          const u32 dv = oldv[j] ^ rowv;
+          const bool clo = (dv & 0xFFFFu) != 0, chi = (dv >> 16) != 0;
+          const u64 mlo = __ballot(clo), mhi = __ballot(chi);
+          if ((mlo | mhi) == 0) continue;
+          u32 nlo, nhi;
+          asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nlo) : "s"(mlo) : "scc");
+          asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nhi) : "s"(mhi) : "scc");
+          const u32 base = (u32)(xhead + xcount), tag = (u32)r << 16;
+          if (clo) xq[(base + mbcnt64(mlo)) & (XQ_CAP - 1)] = (rowv & 0xFFFFu) | tag | ((u32)(2 * lane) << 21);
+          if (chi) xq[(base + nlo + mbcnt64(mhi)) & (XQ_CAP - 1)] = (rowv >> 16) | tag | ((u32)(2 * lane + 1) << 21);
+          xcount += (int)(nlo + nhi);
+        }
       }
     }
   }
