@@ -651,25 +651,25 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
   uint8_t *bseg = p.blur + (size_t)frame * p.blur_frame_stride + (size_t)strip * H * 256;  // this strip's segment (wave-uniform)
   const u32 bo = (u32)(4 * lane);
 
-  auto load_row = [&](int row) -> u32 {  // same input forms as k_front
+  // 12 bytes of interleaved 3-channel data -> the lane's 4 pixels: one channel (IN == 2) or the grey value (IN == 1)
+  auto from3 = [&](u32 d0, u32 d1, u32 d2) -> u32 {
+    if (IN == 2) return __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, selA), selB);
+    const u32 wts = 0x00132607u;
+    const u32 m0 = __builtin_amdgcn_udot4(d0, wts, 0u, false) >> 6;
+    const u32 m1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), wts, 0u, false) >> 6;
+    const u32 m2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), wts, 0u, false) >> 6;
+    const u32 m3 = __builtin_amdgcn_udot4(d2 >> 8, wts, 0u, false) >> 6;
+    return m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+  };
+  auto load_row = [&](int row) -> u32 {  // same input forms as k_front (only the four warm-up rows of a run come this way)
     u32 v = 0;
     if (row >= 0 && row < H && col_any) {
       const uint8_t *rowp = frame_base + (u32)row * in_pitch32;
       u32 lo = ld_off;
       asm volatile("" : "+v"(lo));
-      if (IN == 2) {
+      if (IN != 0) {
         const u32 *q = reinterpret_cast<const u32 *>(rowp + lo);
-        const u32 t = __builtin_amdgcn_perm(q[1], q[0], selA);
-        v = __builtin_amdgcn_perm(q[2], t, selB);
-      } else if (IN == 1) {
-        const u32 *q = reinterpret_cast<const u32 *>(rowp + lo);
-        const u32 d0 = q[0], d1 = q[1], d2 = q[2];
-        const u32 wts = 0x00132607u;
-        const u32 m0 = __builtin_amdgcn_udot4(d0, wts, 0u, false) >> 6;
-        const u32 m1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d1, d0, 3), wts, 0u, false) >> 6;
-        const u32 m2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(d2, d1, 2), wts, 0u, false) >> 6;
-        const u32 m3 = __builtin_amdgcn_udot4(d2 >> 8, wts, 0u, false) >> 6;
-        v = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+        v = from3(q[0], q[1], q[2]);
       } else v = *reinterpret_cast<const u32 *>(rowp + lo);
     }
     return v;
@@ -747,40 +747,42 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
       accumulate(xw[j], Sp);
     }
   }
-  // Plain u8 input: the loads are unconditional (rows clamped to what the run needs, lanes without an image column
-  // read the row's first dword; both are masked when the row is used), each row's register is refilled as soon as it
-  // has been consumed, and a row then waits for the oldest of G loads in flight (vmcnt(G-1)) -- with conditional loads
-  // the compiler can only wait for everything, the wave's stores included (see k_nms).
+  // The loads of the main loop are unconditional (rows clamped to what the run needs, lanes without an image column
+  // read the row's first bytes; both are masked when the row is used), kept as loaded (1 or 3 dwords per row) and
+  // converted when the row is consumed, and each row's registers are refilled as soon as it has been consumed: a row
+  // waits for the oldest of G requests in flight.  With conditional loads the compiler can only wait for everything,
+  // the wave's stores included (see k_nms); converting at the load made the wave wait for each request at once.
+  constexpr int ND = IN == 0 ? 1 : 3;  // dwords per lane and row
   const int rlast = min(H - 1, rend + 1);  // last input row this run needs
   const u32 ld_safe = col_any ? ld_off : 0u;
-  auto load_raw = [&](int row) -> u32 {
+  struct Raw { u32 d[ND]; };
+  auto load_raw = [&](int row) -> Raw {
     u32 lo = ld_safe;
     asm volatile("" : "+v"(lo));
-    return *reinterpret_cast<const u32 *>(frame_base + (u32)min(max(row, 0), rlast) * in_pitch32 + lo);
-  };
-  u32 xn[G];
+    const u32 *q = reinterpret_cast<const u32 *>(frame_base + (u32)min(max(row, 0), rlast) * in_pitch32 + lo);
+    Raw r;
 #pragma unroll
-  for (int j = 0; j < G; ++j) xn[j] = IN == 0 ? load_raw(r0 + 2 + j) : load_row(r0 + 2 + j);
+    for (int i = 0; i < ND; ++i) r.d[i] = q[i];
+    return r;
+  };
+  auto use_raw = [&](int row, const Raw &r) -> u32 {
+    u32 x;
+    if constexpr (IN == 0) x = r.d[0];
+    else x = from3(r.d[0], r.d[ND > 1 ? 1 : 0], r.d[ND > 2 ? 2 : 0]);
+    if ((u32)row >= (u32)H) x = 0;  // wave-uniform: zero padding below the image (above it: the warm-up rows)
+    return x;
+  };
+  Raw xn[G];
+#pragma unroll
+  for (int j = 0; j < G; ++j) xn[j] = load_raw(r0 + 2 + j);
   int wb0 = r0;  // first blur row of the current fix-up window
 #pragma nounroll
   for (int rb0 = r0; rb0 < rend; rb0 += G) {
-    if (IN == 0) {
 #pragma unroll
-      for (int j = 0; j < G; ++j) {
-        u32 x = xn[j];
-        if ((u32)(rb0 + 2 + j) >= (u32)H) x = 0;  // wave-uniform: zero padding below the image (above it: the warm-up rows)
-        xn[j] = load_raw(rb0 + 2 + G + j);
-        blur_row(rb0 + j, rb0 - wb0 + j, x);
-      }
-    } else {
-      u32 xc[G];
-#pragma unroll
-      for (int j = 0; j < G; ++j) xc[j] = xn[j];
-      if (rb0 + G < rend)
-#pragma unroll
-        for (int j = 0; j < G; ++j) xn[j] = load_row(rb0 + 2 + G + j);
-#pragma unroll
-      for (int j = 0; j < G; ++j) blur_row(rb0 + j, rb0 - wb0 + j, xc[j]);
+    for (int j = 0; j < G; ++j) {
+      const u32 x = use_raw(rb0 + 2 + j, xn[j]);
+      xn[j] = load_raw(rb0 + 2 + G + j);
+      blur_row(rb0 + j, rb0 - wb0 + j, x);
     }
     if (rb0 + G - wb0 < BSUB && rb0 + G < rend) continue;
     // fix-up of the window [wb0, rb0 + G): the queued pixels get the literal chain, written over the plane
