@@ -700,6 +700,8 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
     }
   };
 
+  u32 fifteen = 15u;
+  asm volatile("" : "+v"(fifteen));  // the SDWA shift takes its count from a VGPR
   int qn = 0;
   // input row rb + 2 completes blur row rb; `slot` = rb - b0 inside the current fix-up window
   auto blur_row = [&](int rb, int slot, u32 xraw) {
@@ -708,14 +710,16 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
     accumulate(xraw, Sp);
     if (rb < rend) {  // wave-uniform (rb >= r0 >= 0 by construction)
       const u16x2 mlo = { 52759, 0 }, mhi = { 0, 52759 };
-      const u32 t0 = __builtin_amdgcn_udot2(U(Sp[0]), mlo, 0u, false) >> 15;
-      const u32 t1 = __builtin_amdgcn_udot2(U(Sp[0]), mhi, 0u, false) >> 15;
-      const u32 t2 = __builtin_amdgcn_udot2(U(Sp[1]), mlo, 0u, false) >> 15;
-      const u32 t3 = __builtin_amdgcn_udot2(U(Sp[1]), mhi, 0u, false) >> 15;
-      const u32 nf01 = __builtin_amdgcn_perm(t1, t0, 0x04000501u);
-      const u32 nf23 = __builtin_amdgcn_perm(t3, t2, 0x04000501u);
-      const u32 bl = __builtin_amdgcn_perm(nf23, nf01, 0x05040100u) & cmask;
-      const u32 fz = __builtin_amdgcn_perm(nf23, nf01, 0x07060302u);
+      // (S * 52759) >> 15 is 16 bits: quotient byte above fraction byte.  The second pixel of a pair is shifted
+      // straight into the upper half of the first one's register (SDWA), so two v_perm collect the four quotient
+      // and the four fraction bytes.
+      u32 t01 = __builtin_amdgcn_udot2(U(Sp[0]), mlo, 0u, false) >> 15;
+      u32 t23 = __builtin_amdgcn_udot2(U(Sp[1]), mlo, 0u, false) >> 15;
+      const u32 p1 = __builtin_amdgcn_udot2(U(Sp[0]), mhi, 0u, false), p3 = __builtin_amdgcn_udot2(U(Sp[1]), mhi, 0u, false);
+      asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(t01) : "v"(fifteen), "v"(p1));
+      asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(t23) : "v"(fifteen), "v"(p3));
+      const u32 bl = __builtin_amdgcn_perm(t23, t01, 0x07050301u) & cmask;  // bytes f0 q0 f1 q1 | f2 q2 f3 q3 -> q0..q3
+      const u32 fz = __builtin_amdgcn_perm(t23, t01, 0x06040200u);         // -> f0..f3
       const u32 hz = (fz - 0x01010101u) & ~fz & hmask;
       const u64 any = __ballot(hz != 0);
       if (any != 0) {
