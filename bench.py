@@ -185,6 +185,9 @@ def main():
                     out["roofline"]["traffic"] = round(prof["front_kernels_hbm_bytes_per_launch"] / 1e9, 3)
                     out["roofline"]["traffic_unit"] = "GB per launch (2*FETCH_SIZE + WRITE_SIZE, " + os.path.relpath(pf, ROOT) + ")"
                     out["roofline"]["algorithmic_GB_per_launch"] = round(alg_bytes_per_launch / 1e9, 3)
+                    # the same kernels' real HBM traffic against the peak (how busy the memory system is, not a roofline claim)
+                    out["roofline"]["traffic_GBps"] = round(out["roofline"]["traffic"] / (front_ms * 1e-3), 1) if front_ms > 0 else None
+                    out["roofline"]["traffic_frac_of_peak"] = round(out["roofline"]["traffic"] / (front_ms * 1e-3) / HBM_PEAK_GBPS, 4) if front_ms > 0 else None
             except (OSError, KeyError, ValueError):
                 pass
         if not a.no_cpu_baseline and C == 1:
