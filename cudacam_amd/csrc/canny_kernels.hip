@@ -641,7 +641,9 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
     cmask |= in ? (0xFFu << (8 * k)) : 0u;
   }
   const bool own_lane = lane >= 1 && lane <= 62;                // lanes 0 and 63 only feed their neighbours' taps
-  const u32 hmask = own_lane ? (cmask & 0x80808080u) : 0u;      // "undecidable" flag positions this lane is responsible for
+  // "undecidable" flag positions this lane is responsible for: its own 4 pixels, and in the halo lanes the two pixels
+  // next to the strip (k_nms needs 2 valid blur columns beyond each side; all their taps lie inside this wave)
+  const u32 hmask = cmask & (own_lane ? 0x80808080u : lane == 0 ? 0x80800000u : 0x00008080u);
   const bool col_any = cmask != 0;
   const uint8_t *frame_base = p.in + (size_t)in_frame * p.in_frame_stride;
   const u32 in_pitch32 = (u32)p.in_pitch;                       // launch_blur checks H * pitch < 2^32
@@ -808,11 +810,13 @@ __global__ __launch_bounds__(256) void k_blur(const FrontParams p)
       }
     } else {
       const int nrows = min(rb0 + G, rend) - wb0;
+      constexpr int FIXW = STRIP_W + 4;  // the strip's columns and two on each side (bytes 2 .. 253 of a segment row)
 #pragma nounroll
-      for (int e = lane; e < nrows * STRIP_W; e += 64) {
-        const int row = wb0 + e / STRIP_W;
-        const int col = strip * STRIP_W + e % STRIP_W;
-        if (col < W) bseg[(u32)row * 256u + 4u + (u32)(e % STRIP_W)] = (unsigned char)gauss_chain_lds(ring, row, 4u + (u32)(e % STRIP_W));
+      for (int e = lane; e < nrows * FIXW; e += 64) {
+        const int row = wb0 + e / FIXW;
+        const u32 b = 2u + (u32)(e % FIXW);
+        const int col = strip * STRIP_W - STRIP_HALO + (int)b;
+        if (col >= 0 && col < W) bseg[(u32)row * 256u + b] = (unsigned char)gauss_chain_lds(ring, row, b);
       }
     }
     wave_lds_sync();
@@ -858,12 +862,11 @@ __global__ __launch_bounds__(256) void k_nms(const FrontParams p)
   const u32 oknib1 = (lane >= 1 && lane <= 62) ? ((cmask & 1u) | ((cmask >> 7) & 2u) | ((cmask >> 14) & 4u) | ((cmask >> 21) & 8u)) : 0u;
   const u32 oknib = oknib1 | (oknib1 << 8);
   const u32 bm0 = pm0, bm1 = pm1;  // packed-i16 column masks of the two pixel pairs
-  // own columns from this strip's segment; the halo lanes read the dword the neighbouring strip owns
-  // (lane 0 <- strip-1 lane 62, lane 63 <- strip+1 lane 1); lanes without an image column read nothing (0)
   const uint8_t *bframe = p.blur + (size_t)frame * p.blur_frame_stride;  // wave-uniform
   const bool col_any = cmask != 0;  // false for lane 0 of strip 0 and for lanes right of the image (incl. a missing strip+1)
-  const int seg = !col_any ? strip : lane == 0 ? strip - 1 : lane == 63 ? strip + 1 : strip;
-  const u32 bo = (u32)seg * (u32)H * 256u + (!col_any ? (u32)(4 * lane) : lane == 0 ? 248u : lane == 63 ? 4u : (u32)(4 * lane));
+  // every lane reads its own dword of this strip's segment: one aligned 256-byte row per wave.  The halo lanes' two
+  // pixels next to the strip are exact there (k_blur fixes them up like the strip's own), the outer two are never used.
+  const u32 bo = (u32)strip * (u32)H * 256u + (u32)(4 * lane);
   const u32 lane_keep = col_any ? ~0u : 0u;
   const int klast = min(H - 1, rend + 1);  // last blur row this run needs
   // The loads are unconditional -- every lane reads a valid dword of the plane (rows clamped, lanes without an image
