@@ -54,8 +54,7 @@ struct hc_ctx {
   int low = 10, high = 40;
   int nms_saturate = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;  // context stream (own, or the caller's)
-  hipStream_t s_front = nullptr, s_hyst = nullptr;     // pipelined mode: front kernel / hysteresis + expand
-  hipEvent_t ev_in = nullptr;
+  hipStream_t s_hyst = nullptr;                        // pipelined mode: hysteresis + expand (the front kernels stay on `stream`)
   // internal pitched frames
   uint8_t *d_in = nullptr, *d_mono = nullptr, *d_out = nullptr;
   size_t in_pitch = 0, in_fs = 0, mono_pitch = 0, mono_fs = 0, out_pitch = 0, out_fs = 0;
@@ -278,12 +277,11 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     if (int rc = alloc_slot(c, s)) return rc;
     if (int rc = finish_slot(c, s)) return rc;  // the run that used this slot two steps ago
   } else if (int rc = finish_all(c)) return rc;
-  // streams: plain mode = everything on the context stream; pipelined = front on s_front, rest on s_hyst
-  hipStream_t sf = piped ? c->s_front : c->stream, sh = piped ? c->s_hyst : c->stream;
-  if (piped) {  // the front kernel must see the caller's earlier work on the context stream
-    HIPCK(hipEventRecord(c->ev_in, c->stream));
-    HIPCK(hipStreamWaitEvent(sf, c->ev_in, 0));
-  }
+  // streams: the front kernels always run on the context stream, in order with the caller's own work on it (whatever
+  // it did to the input before this call, whatever it does to it afterwards); pipelined mode puts the rest on s_hyst.
+  // (A separate front stream tied to the context stream by events cost a 50 us bubble per run: every cross-stream wait
+  // is a round trip through the command processor.)
+  hipStream_t sf = c->stream, sh = piped ? c->s_hyst : c->stream;
   // unaligned caller buffers go through the internal pitched ones
   const uint8_t *src = in;
   size_t sp = in_pitch, sfs = in_fs;
@@ -391,7 +389,6 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     if (prof) HIPCK(hipEventRecord(ev[2], sf));
     if (piped) {
       HIPCK(hipEventRecord(s.ev_front, sf));
-      HIPCK(hipStreamWaitEvent(c->stream, s.ev_front, 0));  // the caller may now overwrite the input
       HIPCK(hipStreamWaitEvent(sh, s.ev_front, 0));
     }
     HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * FLAG_WORDS, sh));
@@ -476,7 +473,6 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     return false;
   };
   bool good = ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
-  good = good && ok(hipStreamCreateWithFlags(&c->s_front, hipStreamNonBlocking), "hipStreamCreate");
   {
     // pipelined mode: the hysteresis launches are few, small and dependent (latency-bound); at the highest
     // priority their workgroups are placed ahead of the next run's 30k-wave front kernel instead of behind it
@@ -484,7 +480,6 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     good = good && ok(hipStreamCreateWithPriority(&c->s_hyst, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
   }
-  good = good && ok(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming), "hipEventCreate");
   c->stream = c->own_stream;
   // (a BGR row is read in 12-byte groups of 4 pixels: keep room for the ragged last group)
   good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, round_up((size_t)width, 4) * channels, height, max_batch) == HC_OK;
@@ -515,8 +510,7 @@ void hc_destroy(hc_ctx *c)
   free_slot(c->slot[0]);
   free_slot(c->slot[1]);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
-  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
-  for (hipStream_t st : { c->own_stream, c->s_front, c->s_hyst }) if (st) (void)hipStreamDestroy(st);
+  for (hipStream_t st : { c->own_stream, c->s_hyst }) if (st) (void)hipStreamDestroy(st);
   delete c;
 }
 
@@ -656,7 +650,6 @@ int hc_sync(hc_ctx *c)
   if (!c) return fail(HC_E_ARG, "null context");
   HIPCK(hipSetDevice(c->device));
   if (int rc = finish_all(c)) return rc;
-  HIPCK(hipStreamSynchronize(c->s_front));
   HIPCK(hipStreamSynchronize(c->s_hyst));
   HIPCK(hipStreamSynchronize(c->stream));
   while (c->ev_count > 0) {  // collect the event pairs of every run recorded since the last sync

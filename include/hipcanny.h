@@ -121,13 +121,14 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * canonical Mode R reading: the value wraps mod 256 (integer min folds away, low byte stored).
  * 1 = min(g, 255): what the same source line yields when compiled by hipcc for gfx950.
  *
- * HC_OPT_PIPELINE (default 0): throughput mode for back-to-back batches.  1 = the front kernel of
- * run i+1 (own stream) overlaps the hysteresis + expand of run i (second stream, second set of bit
- * planes).  The context stream still orders each run after the caller's earlier work and is held
- * until the run's input has been consumed; the OUTPUT of a run is only guaranteed after hc_sync()
- * (or hc_download).  Results are identical in both modes.  Hand consecutive runs different output buffers (two in
- * turn are enough): a run whose output overlaps the previous run's still gives the exact map, but without the
- * provisional-map shortcut and about 8 % slower.
+ * HC_OPT_PIPELINE (default 0): throughput mode for back-to-back batches.  1 = the front kernels of
+ * run i+1 (on the context stream) overlap the hysteresis + expand of run i (second stream, second set
+ * of bit planes).  The front kernels run in order with the caller's own work on the context stream, so a
+ * run sees what the caller queued before it and the input may be reused by work queued after it; the OUTPUT
+ * of a run is only guaranteed after hc_sync() (or hc_download).  Results are identical in both modes.  Hand
+ * consecutive runs different output buffers (two in turn are enough): a run whose output overlaps the previous
+ * run's still gives the exact map, but without the provisional-map shortcut and a few percent
+ * slower.
  *
  * HC_OPT_PER_CHANNEL (default 0, 3-channel contexts only): 1 = instead of the reference's grey
  * conversion, run the detector on each channel separately (BASELINE config "three-channel,
