@@ -44,13 +44,15 @@ OPT_PIPELINE = 2
 OPT_PER_CHANNEL = 3
 OPT_FRONT_SPLIT = 4
 OPT_L2_GRADIENT = 5
+OPT_DEBUG_TAPS = 6
+TAP_BLUR, TAP_THRESH = 1, 2
 
 # every symbol include/hipcanny.h declares
 ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
-    "hc_host_alloc", "hc_host_free", "hc_profile_get_front",
+    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream",
 ]
 
 _lib = None
@@ -99,6 +101,7 @@ def load_library():
     L.hc_download.argtypes = [vp, vp, sz, sz, i]
     L.hc_sync.argtypes = [vp]
     L.hc_set_stream.argtypes = [vp, vp]
+    L.hc_use_own_stream.argtypes = [vp]
     L.hc_enable_profiling.argtypes = [vp, i]
     L.hc_stage_time_ms.argtypes = [vp, i, C.POINTER(C.c_float)]
     L.hc_profile_get.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_long), i]
@@ -109,6 +112,11 @@ def load_library():
     L.hc_set_tuning.argtypes = [vp, i, i]
     L.hc_set_option.argtypes = [vp, i, i]
     L.hc_selftest.argtypes = [i]
+    L.hc_debug_tap.argtypes = [vp, i, vp, sz, sz, i]
+    L.hc_host_alloc.restype = vp
+    L.hc_host_alloc.argtypes = [sz]
+    L.hc_host_free.restype = None
+    L.hc_host_free.argtypes = [vp]
     L.hc_last_error.restype = C.c_char_p
     L.hc_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
@@ -164,7 +172,11 @@ class Context:
         _ck(self.lib.hc_set_option(self.handle, int(option), int(value)))
 
     def set_stream(self, stream_handle):
+        """Run on the caller's hipStream_t (0 = the null stream, e.g. torch's default current stream)."""
         _ck(self.lib.hc_set_stream(self.handle, C.c_void_p(stream_handle)))
+
+    def use_own_stream(self):
+        _ck(self.lib.hc_use_own_stream(self.handle))
 
     def enable_profiling(self, on):
         _ck(self.lib.hc_enable_profiling(self.handle, int(bool(on))))
@@ -232,6 +244,12 @@ class Context:
         buf = (C.c_uint * (3 * launches))()
         _ck(self.lib.hc_hysteresis_stats(self.handle, buf, 3 * launches))
         return [(buf[3 * k], buf[3 * k + 1], buf[3 * k + 2]) for k in range(launches)]
+
+    def debug_tap(self, what, nframes=1):
+        """The FAST path's own intermediate (TAP_BLUR / TAP_THRESH) of the last HYSTER run; needs OPT_DEBUG_TAPS."""
+        out = np.empty((nframes, self.h, self.w), np.uint8)
+        _ck(self.lib.hc_debug_tap(self.handle, int(what), out.ctypes.data, self.w, self.w * self.h, int(nframes)))
+        return out
 
     def process(self, frames, final_stage=CannyStage.HYSTER):
         """upload -> run -> download convenience."""
@@ -324,8 +342,10 @@ class CannyEdge:
         self._out = self._ctx.download(1)[0]
         if self._profiling:
             tm = TimerManager.Get()
-            for st in (CannyStage.MONO, CannyStage.THRESH, CannyStage.HYSTER):
-                tm.addTime(CANNY_STAGES[st], self._ctx.stage_time_ms(st))
+            for st in CannyStage:  # one sample per stage that ran (cannyEdgeH.cu:415-430); -1 = the run did not execute it
+                ms = self._ctx.stage_time_ms(st)
+                if ms >= 0:
+                    tm.addTime(CANNY_STAGES[st], ms)
 
     def output(self):
         return self._out

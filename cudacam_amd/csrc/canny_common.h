@@ -45,6 +45,8 @@ struct FrontParams {
   // k_nms: when set, the strong pixels are also written as 255 (others 0) into this u8 map -- the provisional edge
   // map the hysteresis then only patches (W % 4 == 0: a lane stores its 4 pixels as one dword)
   uint8_t *prov_out; u32 prov_pitch; size_t prov_fs;
+  // diagnostics (HC_OPT_DEBUG_TAPS): the fused kernel also stores its (fixed-up) blur rows here, plain [frame][H][pitch]
+  uint8_t *dbg_blur; u32 dbg_pitch; size_t dbg_fs;
   u32 wrap_limit;  // S >= wrap_limit: gradient >= 256, the wrap bands apply (0xFFFFFFFF: saturating variant)
 };
 
@@ -65,7 +67,6 @@ struct HystParams {
   uint8_t *out;
   size_t out_pitch, out_frame_stride;
   int W;
-  int debug_skip;  // diagnostics: stage and write back only
   int prov;        // the output already holds 255 for every strong pixel of the input planes (written by k_nms): launch 0 only rewrites rows it changes
   int first_pass;  // the planes come straight from k_front / k_pack: rows are not yet closed under the in-row fill
 };
@@ -79,7 +80,7 @@ struct PackParams {  // tri-state u8 map (0/128/255) -> bit planes
 
 // ---- host-callable launchers (defined in canny_kernels.hip) -----------------------------------
 hipError_t launch_selftest(u32 *d_result, hipStream_t s);
-hipError_t upload_gauss_coeffs(const float gk[25]);
+hipError_t check_gauss_coeffs(const float gk[25]);
 hipError_t launch_front(const FrontParams &p, hipStream_t s);
 hipError_t launch_front_o(const FrontParams &p, hipStream_t s);
 hipError_t launch_blur(const FrontParams &p, hipStream_t s);
@@ -88,7 +89,7 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
 size_t front_lds_bytes();
 int front_run_rows(int subchunks);
-void hyst_tile_geometry(int RD, bool beside_front, int *tile_rows, int *waves);
+void hyst_tile_geometry(int geom, bool beside_front, int *tile_rows, int *waves);
 
 // plain per-stage kernels (exact, unfused): the `finalStage` taps MONO..THRESH of CannyEdge::run
 hipError_t launch_gray(const uint8_t *bgr, size_t bpitch, size_t bfs, uint8_t *mono, size_t mpitch, size_t mfs, int W, int H, int n, hipStream_t s);

@@ -25,8 +25,6 @@ namespace hc {
 typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
-__constant__ float c_gk[25];  // reference: __constant__ float GK[5][5], cannyEdgeD.cu:11
-
 // The same 25 values as compile-time constants: K * (1 / 159.0f), both roundings in binary32 (constant
 // folding is IEEE round-to-nearest).  upload_gauss_coeffs() refuses a host table that differs.
 struct GaussLiterals {
@@ -40,10 +38,12 @@ struct GaussLiterals {
 };
 constexpr GaussLiterals GKC{};
 
-hipError_t upload_gauss_coeffs(const float gk[25])
+// The reference uploads its coefficient table to __constant__ GK[5][5] (cannyEdgeD.cu:11, cannyEdgeH.cu:372-380); here the
+// 25 values are literals of the instruction stream (as __constant__ loads they pinned 25 SGPRs across the hot loops), so
+// the host's table -- computed the reference's way at hc_create -- is only CHECKED against them.
+hipError_t check_gauss_coeffs(const float gk[25])
 {
-  if (memcmp(gk, GKC.v, sizeof(GKC.v)) != 0) return hipErrorInvalidValue;  // the fused kernel's literals would disagree
-  return hipMemcpyToSymbol(HIP_SYMBOL(c_gk), gk, 25 * sizeof(float));
+  return memcmp(gk, GKC.v, sizeof(GKC.v)) == 0 ? hipSuccess : hipErrorInvalidValue;
 }
 
 // ---- cross-lane and packed helpers -------------------------------------------------------------
@@ -452,6 +452,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HC_FRONT_WA
         const int rn = u % 2, rp = (u + 1) % 2;            // d/s ring: new row -> [rn] (holds row k-2), previous row k-1 in [rp]
         const int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;  // S ring: new / centre / up
         const u32 b = reinterpret_cast<const u32 *>(blur_s)[t * 64 + lane];
+        if (p.dbg_blur && k >= r0 && k < rend && lane >= 1 && lane <= 62 && c0 < W)  // diagnostics: the fixed-up blur row (pitch >= round_up(W, 4))
+          *reinterpret_cast<u32 *>(p.dbg_blur + (size_t)frame * p.dbg_fs + (size_t)k * p.dbg_pitch + (u32)c0) = b;
         const u32 A = unpack_lo(b), B = unpack_hi(b);
         const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
         const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
@@ -1542,21 +1544,13 @@ struct HystGeom { int nw, tr, waves; };
 // launches.  4 waves x 32 rows (one wave per SIMD) when it runs beside the next run's front kernels (pipelined mode):
 // a 4-wave workgroup finds a place as soon as one wave slot per SIMD frees up, an 8-wave one has to wait for two --
 // measured 1.7 ms against 4.2 ms for the hysteresis of 1024 frames under overlap.
-static inline HystGeom hyst_geom(int RD, bool beside_front)
+static inline HystGeom hyst_geom(bool beside_front) { return beside_front ? HystGeom{ 1, 32, 4 } : HystGeom{ 1, 32, 8 }; }
+// geom: 0 = by the rule above; otherwise a shape picked by the caller for tuning experiments (encoded rows * 100 + waves:
+// 3208, 3204, 3202, 1608, 3216 -- hc_create reads HC_HYST_GEOM once)
+void hyst_tile_geometry(int geom, bool beside_front, int *tile_rows, int *waves)
 {
-  (void)RD;  // frames wider than 2048 columns are tiled in column panels of the same shape
-  if (const char *e = getenv("HC_HYST_GEOM")) {  // tuning experiments: "32x8", "32x4", "32x2", "16x8", "32x16"
-    if (!strcmp(e, "32x8")) return { 1, 32, 8 };
-    if (!strcmp(e, "32x4")) return { 1, 32, 4 };
-    if (!strcmp(e, "32x2")) return { 1, 32, 2 };
-    if (!strcmp(e, "16x8")) return { 1, 16, 8 };
-    if (!strcmp(e, "32x16")) return { 1, 32, 16 };
-  }
-  return beside_front ? HystGeom{ 1, 32, 4 } : HystGeom{ 1, 32, 8 };
-}
-void hyst_tile_geometry(int RD, bool beside_front, int *tile_rows, int *waves)
-{
-  const HystGeom g = hyst_geom(RD, beside_front);
+  HystGeom g = hyst_geom(beside_front);
+  if (geom == 3208 || geom == 3204 || geom == 3202 || geom == 1608 || geom == 3216) g = HystGeom{ 1, geom / 100, geom % 100 };
   *tile_rows = g.tr;
   *waves = g.waves;
 }
@@ -1721,7 +1715,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   // change.  Waves exchange their boundary rows through LDS between rounds.
   u64 changed = 0;
   u32 colchg = 0;  // bit 0: first column of the panel changed, bit 1: last column
-  for (int round = 0; round < (p.debug_skip ? 0 : 4096); ++round) {
+  for (int round = 0; round < 4096; ++round) {
     u64 round_changed = 0;
     while (dirty) {
       const int r = __builtin_ctzll(dirty);

@@ -95,7 +95,7 @@ namespace cuda
     checkHip(hc_enable_profiling(m_ctx, profiling ? 1 : 0), "hc_enable_profiling");
   }
 
-  void CannyEdge::run(cv::Mat input, cvp::CannyStage finalStage)
+  void CannyEdge::runView(const FrameView &input, cvp::CannyStage finalStage)
   {
     LOG_DEBUG("Start Canny Edge Filter on HIP device");
     if (static_cast<int>(finalStage) < MONO || static_cast<int>(finalStage) > HYSTER) {
@@ -103,25 +103,26 @@ namespace cuda
       return;
     }
     // cannyEdgeH.cu:124-130: a frame whose geometry differs from construction is logged and skipped
-    if (input.rows != m_inputH || input.cols != m_inputW || input.channels() != m_inputNbChannels) {
+    if (input.rows != m_inputH || input.cols != m_inputW || input.channels != m_inputNbChannels) {
       LOG_ERROR("Cannot load image to GPU, specs different since initialization");
       return;
     }
-    if (input.type() != CV_8UC3 && input.type() != CV_8UC1) {
+    if (input.type != CV_8UC3 && input.type != CV_8UC1) {
       LOG_ERROR("Only supporting CV_8UC3 and CV_8UC1 input types for now");
       return;
     }
-    checkHip(hc_upload(m_ctx, input.ptr(), input.step, input.step * static_cast<std::size_t>(input.rows), 1), "hc_upload");
+    checkHip(hc_upload(m_ctx, input.data, input.step, input.step * static_cast<std::size_t>(input.rows), 1), "hc_upload");
     checkHip(hc_run(m_ctx, static_cast<int>(finalStage), 1), "hc_run");
     m_output.resize(static_cast<std::size_t>(m_inputW) * m_inputH);
     checkHip(hc_download(m_ctx, m_output.data(), static_cast<std::size_t>(m_inputW), m_output.size(), 1), "hc_download");
     if (m_isKernelProfilingEnabled) {
-      // the fused kernel covers stages 1-4: its time is booked on the last of them (see hipcanny.h)
+      // one sample per stage that ran, as _endCudaTimer(stage) books them (cannyEdgeH.cu:415-430); how a fused kernel's
+      // time is shared among the stages it covers: hipcanny.h, hc_stage_time_ms
       auto &timers = timerManager::Get();
-      for (int s : { static_cast<int>(MONO), static_cast<int>(THRESH), static_cast<int>(HYSTER) }) {
+      for (int s = static_cast<int>(MONO); s <= static_cast<int>(HYSTER); ++s) {
         float ms = 0.0f;
         checkHip(hc_stage_time_ms(m_ctx, s, &ms), "hc_stage_time_ms");
-        timers.addTime(CANNY_STAGES.at(static_cast<CannyStage>(s)), ms);
+        if (ms >= 0.0f) timers.addTime(CANNY_STAGES.at(static_cast<CannyStage>(s)), ms);
       }
     }
     LOG_DEBUG("End Canny Edge Filter on HIP device");
@@ -136,7 +137,7 @@ cvPipeline::cvPipeline(const unsigned int pbo, const unsigned int inputImageCols
 // the reference calls unique_ptr::release() here and leaks the operator (cvPipeline.cpp:14-17)
 cvPipeline::~cvPipeline() = default;
 
-bool cvPipeline::process(cv::Mat inputImage, CannyStage finalStage)
+bool cvPipeline::processView(const FrameView &inputImage, CannyStage finalStage)
 {
   if (!m_detector) {
     LOG_ERROR("Cannot process the webcam stream, device is not ready.");
@@ -146,11 +147,11 @@ bool cvPipeline::process(cv::Mat inputImage, CannyStage finalStage)
     LOG_ERROR("Blank frame grabbed");
     return false;
   }
-  if (inputImage.type() != CV_8UC3 && inputImage.type() != CV_8UC1) {
+  if (inputImage.type != CV_8UC3 && inputImage.type != CV_8UC1) {
     LOG_ERROR("Only supporting CV_8UC3 and CV_8UC1 input types for now");
     return false;
   }
-  m_detector->run(inputImage, finalStage);
+  m_detector->runView(inputImage, finalStage);
   return true;
 }
 

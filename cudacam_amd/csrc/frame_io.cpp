@@ -42,7 +42,7 @@ namespace io
     }
   }// namespace
 
-  bool readPNM(const std::string &path, cv::Mat &out)
+  bool readPNMRaw(const std::string &path, std::vector<std::uint8_t> &pixels, int &width, int &height, int &channels)
   {
     std::FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return false;
@@ -51,27 +51,27 @@ namespace io
     int w = 0, h = 0, maxval = 0;
     if (m0 == 'P' && (m1 == '5' || m1 == '6') && pnmToken(f, w) && pnmToken(f, h) && pnmToken(f, maxval) && w > 0 && h > 0 && maxval == 255) {
       const int ch = m1 == '5' ? 1 : 3;
-      cv::Mat img(h, w, ch == 1 ? CV_8UC1 : CV_8UC3);
-      ok = true;
-      for (int r = 0; r < h && ok; ++r) ok = std::fread(img.ptr(r), 1, static_cast<std::size_t>(w) * ch, f) == static_cast<std::size_t>(w) * ch;
+      const std::size_t total = static_cast<std::size_t>(w) * ch * static_cast<std::size_t>(h);
+      std::vector<std::uint8_t> img(total);
+      ok = std::fread(img.data(), 1, total, f) == total;
       if (ok && ch == 3)
-        for (int r = 0; r < h; ++r) {
-          std::uint8_t *p = img.ptr(r);
-          for (int c = 0; c < w; ++c) std::swap(p[3 * c], p[3 * c + 2]);// RGB on disk -> BGR in memory, as cv::imread
-        }
-      if (ok) out = img;
+        for (std::size_t i = 0; i + 2 < total; i += 3) std::swap(img[i], img[i + 2]);// RGB on disk -> BGR in memory, as cv::imread
+      if (ok) {
+        pixels.swap(img);
+        width = w; height = h; channels = ch;
+      }
     }
     std::fclose(f);
     return ok;
   }
 
-  bool writePGM(const std::string &path, const cv::Mat &img)
+  bool writePGMRaw(const std::string &path, const std::uint8_t *data, std::size_t step, int width, int height)
   {
-    if (img.empty() || img.channels() != 1) return false;
+    if (!data || width <= 0 || height <= 0 || step < static_cast<std::size_t>(width)) return false;
     std::FILE *f = std::fopen(path.c_str(), "wb");
     if (!f) return false;
-    bool ok = std::fprintf(f, "P5\n%d %d\n255\n", img.cols, img.rows) > 0;
-    for (int r = 0; r < img.rows && ok; ++r) ok = std::fwrite(img.ptr(r), 1, static_cast<std::size_t>(img.cols), f) == static_cast<std::size_t>(img.cols);
+    bool ok = std::fprintf(f, "P5\n%d %d\n255\n", width, height) > 0;
+    for (int r = 0; r < height && ok; ++r) ok = std::fwrite(data + step * static_cast<std::size_t>(r), 1, static_cast<std::size_t>(width), f) == static_cast<std::size_t>(width);
     return std::fclose(f) == 0 && ok;
   }
 

@@ -71,23 +71,37 @@ struct hc_ctx {
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
   size_t bplane_fs = 0, bplane_frames = 0;
+  // HC_OPT_DEBUG_TAPS: copies of the bit planes as the front kernels left them, and (fused kernel) a plain blur plane
+  bool debug_taps = false;
+  u32 *dbg_s = nullptr, *dbg_c = nullptr;
+  uint8_t *dbg_blur = nullptr;
+  int dbg_frames = 0;        // output frames captured by the last run (0: nothing captured)
+  bool dbg_blur_split = false, dbg_blur_valid = false;
   int RD = 0;
   int nstrips = 0, chunk = 0, hyst_launches = 6;
+  // diagnostic environment variables, read ONCE at hc_create (never in the launch path): HC_HYST_DIAG (per-launch
+  // counters for hc_hysteresis_stats; slows the launches), HC_HYST_GEOM (hysteresis workgroup shape, e.g. "32x8")
+  bool hyst_diag = false;
+  int hyst_geom = 0;
   bool hyst_launches_set = false;  // hc_set_tuning called: queue exactly that many launches
   int last_work_launches = 0, last_continued = 0;
   u32 h_stats[3 * 16] = { 0 };
   int uploaded = 0, last_run_n = 0;
   bool profiling = false;
-  // hipEvent ring: 4 events per run (start, after stage 0, after the fused/stage kernels, end)
+  // hipEvent ring: up to EV_PER_RUN events per profiled run.  Interval i = ev[i] -> ev[i + 1] covers the reference stages
+  // in RunProf::mask[i] (one kernel may cover several: its time is divided equally among them, see hc_stage_time_ms)
   static constexpr int EV_RUNS = 256;
+  static constexpr int EV_PER_RUN = 8;
+  struct RunProf { int nint = 0; uint8_t mask[EV_PER_RUN - 1] = { 0 }; uint8_t kind[EV_PER_RUN - 1] = { 0 }; };
+  enum { K_STAGE0 = 0, K_FRONT_A = 1, K_FRONT_B = 2, K_HYST = 3 };  // grey kernel / k_blur / k_nms, the fused front kernel or the tap kernels / hysteresis
   std::vector<hipEvent_t> evpool;
+  std::vector<RunProf> runprof;
   int ev_head = 0, ev_count = 0;  // runs recorded since the last collect
   float stage_ms[6] = { 0, 0, 0, 0, 0, 0 };
-  static constexpr int EV_PER_RUN = 5;  // start, after stage 0, after the front kernels, end, between k_blur and k_nms
+  unsigned stage_ran = 0;         // stages the last profiled run executed (bit per stage)
   double prof_sum[3] = { 0, 0, 0 };
   double prof_split_sum[2] = { 0, 0 };  // k_blur, k_nms (split front path only)
   long prof_split_runs = 0;
-  std::vector<char> ev_has_mid;         // per ring entry: event 4 was recorded
   long prof_runs = 0;
 };
 
@@ -149,6 +163,25 @@ int ensure_blur_plane(hc_ctx *c)
   HIPCK(hipMalloc((void **)&c->d_bplane, c->bplane_fs * frames));
   c->bplane_frames = frames;
   return HC_OK;
+}
+
+int ensure_debug_buffers(hc_ctx *c)
+{
+  if (c->dbg_s) return HC_OK;
+  const size_t frames = (size_t)c->max_batch * (c->per_channel ? 3 : 1);
+  const size_t plane_bytes = sizeof(u32) * (size_t)c->RD * c->H * frames;
+  HIPCK(hipMalloc((void **)&c->dbg_s, plane_bytes));
+  HIPCK(hipMalloc((void **)&c->dbg_c, plane_bytes));
+  HIPCK(hipMalloc((void **)&c->dbg_blur, c->out_fs * frames));
+  return HC_OK;
+}
+
+void free_debug_buffers(hc_ctx *c)
+{
+  for (void *q : { (void *)c->dbg_s, (void *)c->dbg_c, (void *)c->dbg_blur }) (void)hipFree(q);
+  c->dbg_s = c->dbg_c = nullptr;
+  c->dbg_blur = nullptr;
+  c->dbg_frames = 0;
 }
 
 // rows per work item: about 16 rounds of the whole chip (8192 resident waves) when the batch allows it -- the tail of a
@@ -238,7 +271,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   HystParams hp{};
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags; hp.tflags = s.d_tflags;
   // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
-  hyst_tile_geometry(c->RD, small_tiles, &hp.tile_rows, &hp.waves);
+  hyst_tile_geometry(c->hyst_geom, small_tiles, &hp.tile_rows, &hp.waves);
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
   hp.npanels = (c->RD + 63) / 64;
   // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
@@ -247,11 +280,10 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
   hp.prov = s.prov ? 1 : 0;
-  hp.debug_skip = getenv("HC_DEBUG_SKIP_HYST") ? 1 : 0;
   for (int k = 0; k < K; ++k) {
     hp.iter = k;
     // diagnostics cost ~3 same-address atomics per wave (hundreds of microseconds per launch): opt-in only
-    hp.stats = getenv("HC_HYST_DIAG") ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
+    hp.stats = c->hyst_diag ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
     HIPCK(launch_hyst(hp, st));
   }
   HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, st));
@@ -296,12 +328,24 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
 
   const bool prof = c->profiling && c->ev_count < hc_ctx::EV_RUNS;  // ring full: this run goes untimed
   hipEvent_t *ev = nullptr;
+  hc_ctx::RunProf *rp = nullptr;
   if (prof) {
     const size_t slot_i = (size_t)((c->ev_head + c->ev_count) % hc_ctx::EV_RUNS);
     ev = &c->evpool[slot_i * hc_ctx::EV_PER_RUN];
-    c->ev_has_mid[slot_i] = 0;
+    rp = &c->runprof[slot_i];
+    *rp = hc_ctx::RunProf{};
     HIPCK(hipEventRecord(ev[0], sf));
   }
+  // closes the interval that began at the previous event: it covered `mask` (bit per reference stage)
+  auto mark = [&](hipStream_t st, unsigned mask, int kind) -> hipError_t {
+    if (!prof || rp->nint >= hc_ctx::EV_PER_RUN - 1) return hipSuccess;
+    rp->mask[rp->nint] = (uint8_t)mask;
+    rp->kind[rp->nint] = (uint8_t)kind;
+    rp->nint++;
+    return hipEventRecord(ev[rp->nint], st);
+  };
+  constexpr unsigned B_MONO = 1u << HC_STAGE_MONO, B_GAUSS = 1u << HC_STAGE_GAUSSIAN, B_GRAD = 1u << HC_STAGE_GRADIENT,
+                     B_NMS = 1u << HC_STAGE_NMS, B_THR = 1u << HC_STAGE_THRESH, B_HYST = 1u << HC_STAGE_HYSTER;
   // stage 0 (cannyEdgeH.cu:214-227); 1-channel input skips it (the reference's mono path is broken, SURVEY §3 ii)
   const uint8_t *mono = src;
   size_t mp = sp, mfs = sfs;
@@ -316,10 +360,11 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       HIPCK(launch_gray(src, sp, sfs, c->d_mono, c->mono_pitch, c->mono_fs, W, H, n, sf));
       mono = c->d_mono; mp = c->mono_pitch; mfs = c->mono_fs;
     }
+    HIPCK(mark(sf, B_MONO, hc_ctx::K_STAGE0));
   } else if (stage == HC_STAGE_MONO) {
     if (int rc = copy_frames_d2d(c, sf, dst, dp, dfs, src, sp, sfs, (size_t)W, n)) return rc;
+    HIPCK(mark(sf, B_MONO, hc_ctx::K_STAGE0));
   }
-  if (prof) HIPCK(hipEventRecord(ev[1], sf));
 
   if (stage == HC_STAGE_HYSTER) {
     FrontParams fp{};
@@ -343,9 +388,17 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     // hysteresis may still be patching it, and a late patch would survive into this run's map.
     const uintptr_t o0 = (uintptr_t)dst, o1 = o0 + (size_t)n_out * dfs;
     const bool out_overlap = piped && c->prev_out0 < o1 && o0 < c->prev_out1;
+    // ... and that run is completed first: should its queued launches not have reached the fixpoint, its host-side
+    // continuation rewrites whole maps (finish_slot) and would otherwise land on top of this run's result
+    if (out_overlap)
+      if (int rc = finish_slot(c, c->slot[c->cur ^ 1])) return rc;
     s.prov = piped && !out_overlap && W % 4 == 0 && (split || c->mode == HC_MODE_O);
     if (piped) { c->prev_out0 = o0; c->prev_out1 = o1; }
     if (s.prov) { fp.prov_out = dst; fp.prov_pitch = (u32)dp; fp.prov_fs = dfs; }
+    if (c->debug_taps) {
+      if (int rc = ensure_debug_buffers(c)) return rc;
+      if (!split) { fp.dbg_blur = c->dbg_blur; fp.dbg_pitch = (u32)c->out_pitch; fp.dbg_fs = c->out_fs; }
+    }
     if (split) {  // k_blur + k_nms through the blur plane
       if (int rc = ensure_blur_plane(c)) return rc;
       fp.blur = c->d_bplane; fp.blur_frame_stride = c->bplane_fs;
@@ -373,20 +426,30 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.total_items = n_out * fp.nstrips * fp.nchunks;
       if (sp < round_up((size_t)W, 4)) return fail(HC_E_ARG, "mode O needs an input pitch of at least round_up(width, 4)");
       HIPCK(launch_front_o(fp, sf));
+      HIPCK(mark(sf, B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));  // cv::Canny has no blur stage
     } else {
       band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);
       band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
       fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
+      const unsigned b_mono = fuse_bgr ? B_MONO : 0u;  // stage 0 fused into the blur's load (per-channel mode has no grey stage)
       if (split) {
         HIPCK(launch_blur(fp, sf));
-        if (prof) {
-          HIPCK(hipEventRecord(ev[4], sf));
-          c->ev_has_mid[(size_t)(ev - c->evpool.data()) / hc_ctx::EV_PER_RUN] = 1;
-        }
+        HIPCK(mark(sf, b_mono | B_GAUSS, hc_ctx::K_FRONT_A));
         HIPCK(launch_nms(fp, sf));
-      } else HIPCK(launch_front(fp, sf));
+        HIPCK(mark(sf, B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
+      } else {
+        HIPCK(launch_front(fp, sf));
+        HIPCK(mark(sf, b_mono | B_GAUSS | B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
+      }
     }
-    if (prof) HIPCK(hipEventRecord(ev[2], sf));
+    if (c->debug_taps) {  // what the front kernels hand to the hysteresis (which updates the STRONG plane in place)
+      const size_t bytes = sizeof(u32) * (size_t)c->RD * H * (size_t)n_out;
+      HIPCK(hipMemcpyAsync(c->dbg_s, s.d_sbits, bytes, hipMemcpyDeviceToDevice, sf));
+      HIPCK(hipMemcpyAsync(c->dbg_c, s.d_cbits, bytes, hipMemcpyDeviceToDevice, sf));
+      c->dbg_frames = n_out;
+      c->dbg_blur_split = split;
+      c->dbg_blur_valid = c->mode == HC_MODE_R;
+    }
     if (piped) {
       HIPCK(hipEventRecord(s.ev_front, sf));
       HIPCK(hipStreamWaitEvent(sh, s.ev_front, 0));
@@ -398,25 +461,37 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     const size_t bp = c->out_pitch, bfs = c->out_fs;  // scratch planes share the output geometry
     uint8_t *blur = stage == HC_STAGE_GAUSSIAN ? dst : c->d_blur;
     const size_t blp = stage == HC_STAGE_GAUSSIAN ? dp : bp, blfs = stage == HC_STAGE_GAUSSIAN ? dfs : bfs;
+    // every plain kernel is booked on its own stage, as the reference's _endCudaTimer(stage) does (cannyEdgeH.cu:415-430)
     HIPCK(launch_gauss(mono, mp, mfs, blur, blp, blfs, W, H, n, sf));
+    HIPCK(mark(sf, B_GAUSS, hc_ctx::K_FRONT_B));
     if (stage >= HC_STAGE_GRADIENT) {
       HIPCK(launch_sobel(blur, blp, blfs, c->d_sx, c->d_sy, bp, bfs, W, H, n, sf));
       if (stage == HC_STAGE_GRADIENT) HIPCK(launch_graddisp(c->d_sx, c->d_sy, bp, bfs, dst, dp, dfs, W, H, n, sf));
-      else {
+      HIPCK(mark(sf, B_GRAD, hc_ctx::K_FRONT_B));
+      if (stage > HC_STAGE_GRADIENT) {
         uint8_t *nms = stage == HC_STAGE_NMS ? dst : c->d_nms;
         const size_t np = stage == HC_STAGE_NMS ? dp : bp, nfs = stage == HC_STAGE_NMS ? dfs : bfs;
         HIPCK(launch_nms(c->d_sx, c->d_sy, bp, bfs, nms, np, nfs, W, H, n, c->nms_saturate, sf));
-        if (stage == HC_STAGE_THRESH) HIPCK(launch_thresh(nms, np, nfs, dst, dp, dfs, W, H, n, c->low, c->high, sf));
+        HIPCK(mark(sf, B_NMS, hc_ctx::K_FRONT_B));
+        if (stage == HC_STAGE_THRESH) {
+          HIPCK(launch_thresh(nms, np, nfs, dst, dp, dfs, W, H, n, c->low, c->high, sf));
+          HIPCK(mark(sf, B_THR, hc_ctx::K_FRONT_B));
+        }
       }
     }
-    if (prof) HIPCK(hipEventRecord(ev[2], sf));
-  } else if (prof) HIPCK(hipEventRecord(ev[2], sf));
+  }
 
   if (out_internal) {
     if (int rc = copy_frames_d2d(c, sh, out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)W, n_out)) return rc;
     if (s.pending) { s.copy_dst = out; s.copy_pitch = out_pitch; s.copy_fs = out_fs; }
   }
-  if (prof) { HIPCK(hipEventRecord(ev[3], sh)); c->ev_count++; }
+  if (prof) {
+    // the hysteresis (and the copy-out of an unaligned caller buffer) end the run; for the earlier stages the copy-out
+    // belongs to the last stage that ran
+    if (stage == HC_STAGE_HYSTER) HIPCK(mark(sh, B_HYST, hc_ctx::K_HYST));
+    else if (out_internal) HIPCK(mark(sh, 1u << stage, hc_ctx::K_FRONT_B));
+    c->ev_count++;
+  }
   if (stage == HC_STAGE_HYSTER) HIPCK(hipEventRecord(s.ev_done, sh));
   if (piped) c->cur ^= 1;
   c->last_run_n = n_out;
@@ -481,13 +556,18 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     good = good && ok(hipStreamCreateWithPriority(&c->s_hyst, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
   }
   c->stream = c->own_stream;
+  c->hyst_diag = getenv("HC_HYST_DIAG") != nullptr;
+  if (const char *e = getenv("HC_HYST_GEOM")) {
+    int tr = 0, wv = 0;
+    if (sscanf(e, "%dx%d", &tr, &wv) == 2) c->hyst_geom = tr * 100 + wv;
+  }
   // (a BGR row is read in 12-byte groups of 4 pixels: keep room for the ragged last group)
   good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, round_up((size_t)width, 4) * channels, height, max_batch) == HC_OK;
   good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch) == HC_OK;
   if (good && channels == 3) good = alloc_frames(&c->d_mono, &c->mono_pitch, &c->mono_fs, (size_t)width, height, max_batch) == HC_OK;
   good = good && alloc_slot(c, c->slot[0]) == HC_OK;
   c->evpool.assign((size_t)hc_ctx::EV_RUNS * hc_ctx::EV_PER_RUN, nullptr);
-  c->ev_has_mid.assign((size_t)hc_ctx::EV_RUNS, 0);
+  c->runprof.assign((size_t)hc_ctx::EV_RUNS, hc_ctx::RunProf{});
   for (size_t i = 0; good && i < c->evpool.size(); ++i) good = ok(hipEventCreate(&c->evpool[i]), "hipEventCreate");
   if (good) {
     // cannyEdgeH.cu:372-380: float coefficients K * (1 / 159.0f), computed in binary32 on the host
@@ -495,7 +575,7 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     static const int K[25] = { 2, 4, 5, 4, 2, 4, 9, 12, 9, 4, 5, 12, 15, 12, 5, 4, 9, 12, 9, 4, 2, 4, 5, 4, 2 };
     volatile float r = 1 / 159.0f;
     for (int i = 0; i < 25; ++i) { volatile float k = (float)K[i]; volatile float v = k * r; gk[i] = v; }
-    good = ok(upload_gauss_coeffs(gk), "hipMemcpyToSymbol(GK)");
+    good = ok(check_gauss_coeffs(gk), "Gaussian coefficient table differs from the kernels' literals");
   }
   if (!good) { hc_destroy(c); return nullptr; }
   return c;
@@ -509,6 +589,7 @@ void hc_destroy(hc_ctx *c)
   for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_bplane }) (void)hipFree(q);
   free_slot(c->slot[0]);
   free_slot(c->slot[1]);
+  free_debug_buffers(c);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
   for (hipStream_t st : { c->own_stream, c->s_hyst }) if (st) (void)hipStreamDestroy(st);
   delete c;
@@ -537,7 +618,15 @@ int hc_set_stream(hc_ctx *c, void *s)
 {
   if (!c) return fail(HC_E_ARG, "null context");
   if (int rc = finish_all(c)) return rc;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
+  c->stream = (hipStream_t)s;  // 0 = the null stream itself (ordered with everything the caller queued on it)
+  return HC_OK;
+}
+
+int hc_use_own_stream(hc_ctx *c)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (int rc = finish_all(c)) return rc;
+  c->stream = c->own_stream;
   return HC_OK;
 }
 
@@ -569,6 +658,7 @@ int hc_set_option(hc_ctx *c, int option, int value)
       (void)hipFree(c->d_out);
       c->d_out = nullptr;
       c->per_channel = value != 0;
+      free_debug_buffers(c);
       if (c->d_bplane) { (void)hipFree(c->d_bplane); c->d_bplane = nullptr; c->bplane_frames = 0; }
       if (alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)c->W, c->H, c->max_batch * (c->per_channel ? 3 : 1)) != HC_OK) return HC_E_HIP;
       if (alloc_slot(c, c->slot[0]) != HC_OK) return HC_E_HIP;
@@ -579,6 +669,9 @@ int hc_set_option(hc_ctx *c, int option, int value)
   } else if (option == HC_OPT_L2_GRADIENT) {
     if (c->mode != HC_MODE_O) return fail(HC_E_ARG, "HC_OPT_L2_GRADIENT applies to mode O contexts");
     c->l2gradient = value != 0;
+  } else if (option == HC_OPT_DEBUG_TAPS) {
+    c->debug_taps = value != 0;
+    c->dbg_frames = 0;
   } else if (option == HC_OPT_PIPELINE) {
     HIPCK(hipSetDevice(c->device));
     if (value && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;
@@ -617,6 +710,7 @@ int hc_run_device(hc_ctx *c, const void *d_in, size_t in_pitch, size_t in_fs, vo
   if (final_stage < HC_STAGE_MONO || final_stage > HC_STAGE_HYSTER) return fail(HC_E_ARG, "Canny Stage Not Recognized");
   if (n <= 0 || n > c->max_batch) return fail(HC_E_ARG, "hc_run_device: nframes out of range");
   if (in_pitch < (size_t)c->W * c->C || out_pitch < (size_t)c->W) return fail(HC_E_ARG, "hc_run_device: pitch smaller than a row");
+  if (n > 1 && (in_fs < in_pitch * (size_t)c->H || out_fs < out_pitch * (size_t)c->H)) return fail(HC_E_ARG, "hc_run_device: frame stride smaller than a frame");
   HIPCK(hipSetDevice(c->device));
   return run_impl(c, (const uint8_t *)d_in, in_pitch, in_fs, (uint8_t *)d_out, out_pitch, out_fs, n, final_stage);
 }
@@ -625,6 +719,8 @@ int hc_hysteresis_device(hc_ctx *c, const void *d_thresh, size_t in_pitch, size_
 {
   if (!c || !d_thresh || !d_out) return fail(HC_E_ARG, "hc_hysteresis_device: null argument");
   if (n <= 0 || n > c->max_batch) return fail(HC_E_ARG, "hc_hysteresis_device: nframes out of range");
+  if (in_pitch < (size_t)c->W || out_pitch < (size_t)c->W) return fail(HC_E_ARG, "hc_hysteresis_device: pitch smaller than a row");
+  if (n > 1 && (in_fs < in_pitch * (size_t)c->H || out_fs < out_pitch * (size_t)c->H)) return fail(HC_E_ARG, "hc_hysteresis_device: frame stride smaller than a frame");
   HIPCK(hipSetDevice(c->device));
   if (int rc = finish_all(c)) return rc;
   Slot &s = c->slot[0];
@@ -652,24 +748,27 @@ int hc_sync(hc_ctx *c)
   if (int rc = finish_all(c)) return rc;
   HIPCK(hipStreamSynchronize(c->s_hyst));
   HIPCK(hipStreamSynchronize(c->stream));
-  while (c->ev_count > 0) {  // collect the event pairs of every run recorded since the last sync
+  while (c->ev_count > 0) {  // collect the event intervals of every run recorded since the last sync
     hipEvent_t *e = &c->evpool[(size_t)c->ev_head * hc_ctx::EV_PER_RUN];
-    float a = 0, b = 0, d = 0;
-    HIPCK(hipEventElapsedTime(&a, e[0], e[1]));
-    HIPCK(hipEventElapsedTime(&b, e[1], e[2]));
-    HIPCK(hipEventElapsedTime(&d, e[2], e[3]));
-    if (c->ev_has_mid[(size_t)c->ev_head]) {
-      float kb = 0, kn = 0;
-      HIPCK(hipEventElapsedTime(&kb, e[1], e[4]));
-      HIPCK(hipEventElapsedTime(&kn, e[4], e[2]));
-      c->prof_split_sum[0] += kb; c->prof_split_sum[1] += kn;
-      c->prof_split_runs++;
-    }
+    const hc_ctx::RunProf &rp = c->runprof[(size_t)c->ev_head];
     for (float &m : c->stage_ms) m = 0;
-    c->stage_ms[HC_STAGE_MONO] = a;
-    c->stage_ms[HC_STAGE_THRESH] = b;
-    c->stage_ms[HC_STAGE_HYSTER] = d;
-    c->prof_sum[0] += a; c->prof_sum[1] += b; c->prof_sum[2] += d;
+    c->stage_ran = 0;
+    bool has_a = false;
+    for (int i = 0; i < rp.nint; ++i) has_a = has_a || rp.kind[i] == hc_ctx::K_FRONT_A;
+    for (int i = 0; i < rp.nint; ++i) {
+      float t = 0;
+      HIPCK(hipEventElapsedTime(&t, e[i], e[i + 1]));
+      const unsigned mask = rp.mask[i];
+      const int nst = __builtin_popcount(mask);
+      for (int st = 0; st < 6; ++st)
+        if (mask >> st & 1u) c->stage_ms[st] += t / (float)nst;
+      c->stage_ran |= mask;
+      const int k = rp.kind[i];
+      c->prof_sum[k == hc_ctx::K_STAGE0 ? 0 : k == hc_ctx::K_HYST ? 2 : 1] += t;
+      if (k == hc_ctx::K_FRONT_A) c->prof_split_sum[0] += t;
+      else if (k == hc_ctx::K_FRONT_B && has_a) c->prof_split_sum[1] += t;
+    }
+    if (has_a) c->prof_split_runs++;
     c->prof_runs++;
     c->ev_head = (c->ev_head + 1) % hc_ctx::EV_RUNS;
     c->ev_count--;
@@ -721,7 +820,7 @@ int hc_profile_get_front(hc_ctx *c, double sum_ms[2], long *nruns)
 int hc_stage_time_ms(hc_ctx *c, int stage, float *ms)
 {
   if (!c || !ms || stage < 0 || stage > 5) return fail(HC_E_ARG, "hc_stage_time_ms: bad argument");
-  *ms = c->stage_ms[stage];
+  *ms = (c->stage_ran >> stage & 1u) ? c->stage_ms[stage] : -1.0f;
   return HC_OK;
 }
 
@@ -734,6 +833,46 @@ int hc_device_ptrs(hc_ctx *c, void **d_in, void **d_out, size_t *in_pitch, size_
   if (out_pitch) *out_pitch = c->out_pitch;
   if (in_fs) *in_fs = c->in_fs;
   if (out_fs) *out_fs = c->out_fs;
+  return HC_OK;
+}
+
+int hc_debug_tap(hc_ctx *c, int what, uint8_t *host, size_t row_stride, size_t frame_stride, int n)
+{
+  if (!c || !host) return fail(HC_E_ARG, "hc_debug_tap: null argument");
+  if (what != HC_TAP_BLUR && what != HC_TAP_THRESH) return fail(HC_E_ARG, "hc_debug_tap: unknown tap");
+  if (row_stride < (size_t)c->W) return fail(HC_E_ARG, "hc_debug_tap: row_stride smaller than a row");
+  if (int rc = hc_sync(c)) return rc;
+  if (!c->debug_taps || n <= 0 || n > c->dbg_frames) return fail(HC_E_STATE, "hc_debug_tap: set HC_OPT_DEBUG_TAPS and run HC_STAGE_HYSTER first");
+  const int W = c->W, H = c->H;
+  if (what == HC_TAP_THRESH) {
+    const size_t words = (size_t)c->RD * H * (size_t)n;
+    std::vector<u32> sb(words), cb(words);
+    HIPCK(hipMemcpy(sb.data(), c->dbg_s, words * 4, hipMemcpyDeviceToHost));
+    HIPCK(hipMemcpy(cb.data(), c->dbg_c, words * 4, hipMemcpyDeviceToHost));
+    for (int f = 0; f < n; ++f)
+      for (int r = 0; r < H; ++r) {
+        const u32 *srow = &sb[((size_t)f * H + r) * c->RD], *crow = &cb[((size_t)f * H + r) * c->RD];
+        uint8_t *o = host + frame_stride * f + row_stride * r;
+        for (int x = 0; x < W; ++x) {
+          const u32 sbit = (srow[x >> 5] >> (x & 31)) & 1u, cbit = (crow[x >> 5] >> (x & 31)) & 1u;
+          o[x] = sbit ? 255 : cbit ? 128 : 0;
+        }
+      }
+    return HC_OK;
+  }
+  if (!c->dbg_blur_valid) return fail(HC_E_STATE, "hc_debug_tap: the last run computed no blur (mode O)");
+  if (c->dbg_blur_split) {  // [frame][strip][H][256]: bytes 4..251 of a segment row are the strip's 248 columns
+    std::vector<uint8_t> seg((size_t)H * 256);
+    for (int f = 0; f < n; ++f)
+      for (int st = 0; st < c->nstrips; ++st) {
+        HIPCK(hipMemcpy(seg.data(), c->d_bplane + c->bplane_fs * f + (size_t)st * H * 256, seg.size(), hipMemcpyDeviceToHost));
+        const int x0 = st * STRIP_W, nx = std::min(STRIP_W, W - x0);
+        for (int r = 0; r < H; ++r) std::memcpy(host + frame_stride * f + row_stride * r + x0, &seg[(size_t)r * 256 + 4], (size_t)nx);
+      }
+  } else {
+    for (int f = 0; f < n; ++f)
+      HIPCK(hipMemcpy2D(host + frame_stride * f, row_stride, c->dbg_blur + c->out_fs * f, c->out_pitch, (size_t)W, (size_t)H, hipMemcpyDeviceToHost));
+  }
   return HC_OK;
 }
 

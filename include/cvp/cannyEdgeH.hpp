@@ -13,6 +13,7 @@
 
 #include "cvmat_min.hpp"
 #include "define.hpp"
+#include "frameView.hpp"
 
 struct hc_ctx;
 
@@ -28,7 +29,10 @@ namespace cuda
     CannyEdge(const CannyEdge &) = delete;
     CannyEdge &operator=(const CannyEdge &) = delete;
 
-    void run(cv::Mat input, cvp::CannyStage finalStage);
+    // Reference signature (src/cvp/cannyEdgeH.hpp:23).  Inline on purpose: cv::Mat never crosses the library boundary
+    // (frameView.hpp); the compiled entry point is runView.
+    void run(cv::Mat input, cvp::CannyStage finalStage) { runView(viewOf(input), finalStage); }
+    void runView(const FrameView &input, cvp::CannyStage finalStage);
 
     void setLowThreshold(unsigned char low);
     unsigned char getLowThreshold() const { return m_lowThresh; }

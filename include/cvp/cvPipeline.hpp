@@ -10,6 +10,7 @@
 
 #include "cvmat_min.hpp"  // cv::Mat: OpenCV's when available, a minimal stand-in otherwise
 #include "define.hpp"     // cvp::CannyStage
+#include "frameView.hpp"  // what actually crosses the library boundary
 
 namespace cvp
 {
@@ -28,7 +29,9 @@ public:
 
   // One frame through the detector up to `finalStage`.  Returns false -- and logs, as src/cvp/cvPipeline.cpp:27-36
   // does -- for an empty frame or a type other than CV_8UC1 / CV_8UC3; true otherwise.
-  bool process(cv::Mat inputImage, CannyStage finalStage);
+  // Inline on purpose: cv::Mat never crosses the library boundary (frameView.hpp); the compiled entry point is processView.
+  bool process(cv::Mat inputImage, CannyStage finalStage) { return processView(viewOf(inputImage), finalStage); }
+  bool processView(const FrameView &inputImage, CannyStage finalStage);
 
   // Double-threshold limits, clamped against each other (src/cvp/cannyEdgeH.hpp:25-29).
   unsigned char getLowThreshold() const;

@@ -11,6 +11,9 @@
 //                                   uploads and slot k-1 downloads.  Frames go in in order and come out in order.
 #pragma once
 #include "cvmat_min.hpp"
+#include "frameView.hpp"
+
+#include <algorithm>
 
 #include <cstdint>
 #include <functional>
@@ -24,9 +27,28 @@ namespace cvp
 namespace io
 {
   // Binary PNM (P5: 8-bit grey -> CV_8UC1, P6: 8-bit RGB -> CV_8UC3 in B,G,R order).  maxval must be 255.
-  bool readPNM(const std::string &path, cv::Mat &out);
+  // The compiled entry points take plain buffers; the cv::Mat forms below are inline (frameView.hpp: a Mat never
+  // crosses the library boundary).  pixels: tight rows of width * channels bytes.
+  bool readPNMRaw(const std::string &path, std::vector<std::uint8_t> &pixels, int &width, int &height, int &channels);
+  bool writePGMRaw(const std::string &path, const std::uint8_t *data, std::size_t step, int width, int height);
+  inline bool readPNM(const std::string &path, cv::Mat &out)
+  {
+    std::vector<std::uint8_t> px;
+    int w = 0, h = 0, ch = 0;
+    if (!readPNMRaw(path, px, w, h, ch)) return false;
+    cv::Mat img(h, w, ch == 1 ? CV_8UC1 : CV_8UC3);
+    const std::size_t row = static_cast<std::size_t>(w) * static_cast<std::size_t>(ch);
+    for (int r = 0; r < h; ++r) std::copy(px.begin() + static_cast<std::ptrdiff_t>(row * r), px.begin() + static_cast<std::ptrdiff_t>(row * (r + 1)), img.ptr(r));
+    out = img;
+    return true;
+  }
   // 8-bit single-channel image as binary PGM.
-  bool writePGM(const std::string &path, const cv::Mat &img);
+  inline bool writePGM(const std::string &path, const cv::Mat &img)
+  {
+    const FrameView v = viewOf(img);
+    if (v.empty() || v.channels != 1) return false;
+    return writePGMRaw(path, v.data, v.step, v.cols, v.rows);
+  }
 
   class FrameStreamer
   {

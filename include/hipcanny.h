@@ -83,13 +83,25 @@ int hc_download(hc_ctx *ctx, uint8_t *host, size_t row_stride, size_t frame_stri
 /* Waits for the context stream; also completes the rare hysteresis continuation. */
 int hc_sync(hc_ctx *ctx);
 
-/* Use an external HIP stream (e.g. torch's current stream) instead of the context's own. NULL restores it. */
+/* Run on the caller's HIP stream instead of the context's own: `hip_stream` is a hipStream_t handle, and 0 / NULL
+ * means what it means to HIP -- the device's null (legacy default) stream, which is also what
+ * torch.cuda.current_stream().cuda_stream is unless the caller switched streams.  Front kernels, uploads and
+ * (outside pipelined mode) the hysteresis are then queued on that stream, in order with the caller's own work on
+ * it: a run sees everything queued before it.  The context's own stream is created non-blocking, i.e. it does NOT
+ * synchronise with the null stream; hc_use_own_stream() goes back to it. */
 int hc_set_stream(hc_ctx *ctx, void *hip_stream);
+int hc_use_own_stream(hc_ctx *ctx);
 
 /* Replaces enableKernelProfiling / _startCudaTimer / _endCudaTimer (cannyEdgeH.hpp:31-32,
- * cannyEdgeH.cu:409-430): when enabled, hc_run records hipEvents per stage group; hc_stage_time_ms
- * returns the last run's time attributed to `stage` (the fused kernel's time is reported under
- * HC_STAGE_THRESH, hysteresis under HC_STAGE_HYSTER).  Off by default on the batch path. */
+ * cannyEdgeH.cu:409-430): when enabled, hc_run brackets every kernel with hipEvents; after hc_sync,
+ * hc_stage_time_ms returns the last profiled run's time attributed to `stage`, or -1 when that run did not execute the
+ * stage (final_stage below it, or stage 0 on 1-channel input) -- book a sample only for times >= 0, as the reference
+ * books a stage only when it ran.  Attribution: the plain per-stage kernels behind final_stage < HYSTER each have their
+ * own interval.  On the HYSTER fast path one kernel covers several reference stages and has no internal boundary to
+ * time: k_blur covers MONO (3-channel input) + GAUSSIAN, k_nms covers GRADIENT + NMS + THRESH, a fused front kernel
+ * covers all of them, k_front_o (mode O) GRADIENT + NMS + THRESH; a kernel's time is divided EQUALLY among the stages
+ * it covers, so every stage that ran shows a non-zero share and the sum over stages -- what the reference's UI totals
+ * up to the selected stage (src/imgui/imguiApp.cpp:364-376) -- is the measured time.  Off by default on the batch path. */
 int hc_enable_profiling(hc_ctx *ctx, int on);
 int hc_stage_time_ms(hc_ctx *ctx, int stage, float *ms);
 /* Sums over every profiled run since the last reset (up to 256 runs may be in flight between
@@ -141,8 +153,23 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  *
  * HC_OPT_L2_GRADIENT (default 0, Mode O contexts): cv::Canny's `L2gradient` argument: magnitude dx^2 + dy^2
  * compared with the squared thresholds instead of |dx| + |dy|. */
-enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5 };
+/*
+ * HC_OPT_DEBUG_TAPS (default 0): parity-test diagnostics.  1 = every HC_STAGE_HYSTER run keeps a copy of what the
+ * FAST path's front kernels produced -- the STRONG and CANDIDATE bit planes as they are handed to the hysteresis,
+ * and the blur plane (Mode R) -- for hc_debug_tap().  Costs two plane copies per run; never set it when timing. */
+enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
+
+/* The fast path's own intermediates of the last HC_STAGE_HYSTER run (HC_OPT_DEBUG_TAPS must have been set before it),
+ * as tight-or-strided host u8 images, one per output frame:
+ *   HC_TAP_BLUR       the Gaussian blur the front kernels computed (reference: gaussianFilter5x5 output,
+ *                     src/cvp/cannyEdgeD.cu:72-118); Mode R only
+ *   HC_TAP_THRESH     the double-threshold map 0 / 128 / 255 (doubleThreshold output, cannyEdgeD.cu:273-293) rebuilt
+ *                     from the two bit planes: 255 = STRONG bit, 128 = CANDIDATE bit only
+ * These are NOT the plain per-stage kernels behind hc_run(final_stage < HYSTER): they read back what k_blur / k_nms /
+ * k_front / k_front_o wrote, so that the parity tests can check the fast path stage by stage. */
+enum { HC_TAP_BLUR = 1, HC_TAP_THRESH = 2 };
+int hc_debug_tap(hc_ctx *ctx, int what, uint8_t *host, size_t row_stride, size_t frame_stride, int nframes);
 
 /* Page-locked host memory for frame staging: hc_upload / hc_download on such buffers are true asynchronous DMA
  * (the reference uploads from pageable cv::Mat memory with a blocking cudaMemcpy2D, cannyEdgeH.cu:136/144).

@@ -398,6 +398,14 @@ static inline int pxr(const uint8_t *img, size_t stride, int w, int h, int cn, i
 int orc_canny_o(const uint8_t *in, size_t stride, int w, int h, int channels, double low_thresh, double high_thresh,
                 int l2gradient, uint8_t *edges)
 {
+  return orc_canny_o_ex(in, stride, w, h, channels, low_thresh, high_thresh, l2gradient, edges, NULL);
+}
+
+/* premap (optional): the map as it stands after non-maximum suppression and the two thresholds, before the flood
+ * (canny.cpp's `map` with 2 -> 255 seed, 0 -> 128 candidate, 1 -> 0): what the HIP front kernel's bit planes hold. */
+int orc_canny_o_ex(const uint8_t *in, size_t stride, int w, int h, int channels, double low_thresh, double high_thresh,
+                   int l2gradient, uint8_t *edges, uint8_t *premap)
+{
   if (w <= 0 || h <= 0 || (channels != 1 && channels != 3)) return -1;
   if (low_thresh > high_thresh) { double t = low_thresh; low_thresh = high_thresh; high_thresh = t; }
   if (l2gradient) {
@@ -452,6 +460,8 @@ int orc_canny_o(const uint8_t *in, size_t stride, int w, int h, int channels, do
       else map[(size_t)r * w + c] = 0;
     }
 #undef M
+  if (premap)
+    for (size_t i = 0; i < n; ++i) premap[i] = map[i] == 2 ? 255 : map[i] == 0 ? 128 : 0;
   while (sp) {
     int idx = stack[--sp];
     int r = idx / w, c = idx % w;

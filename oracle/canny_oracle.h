@@ -99,6 +99,9 @@ int orc_canny_r_batch(const uint8_t *in, int w, int h, int nframes, int low, int
 /* OpenCV 4.x modules/imgproc/src/canny.cpp semantics (NOT under /root/reference; unpinned). */
 int orc_canny_o(const uint8_t *in, size_t stride, int w, int h, int channels, double low, double high,
                 int l2gradient, uint8_t *edges);
+/* The same, also returning the tri-state map before the flood (NULL: not wanted): 255 seed, 128 candidate, 0 none. */
+int orc_canny_o_ex(const uint8_t *in, size_t stride, int w, int h, int channels, double low, double high,
+                   int l2gradient, uint8_t *edges, uint8_t *premap);
 int orc_canny_o_batch(const uint8_t *in, int w, int h, int nframes, double low, double high, int l2gradient,
                       uint8_t *edges, int threads);
 

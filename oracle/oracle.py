@@ -45,6 +45,7 @@ def lib():
         L.orc_grad_float.restype = C.c_float
         L.orc_hysteresis.restype = C.c_long
         L.orc_canny_o.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _u8p]
+        L.orc_canny_o_ex.argtypes = [_u8p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _u8p, _u8p]
         L.orc_canny_o_batch.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, _u8p, C.c_int]
         _lib = L
     return _lib
@@ -170,6 +171,19 @@ def canny_o(img, low=50, high=150, l2gradient=False):
     if rc:
         raise ValueError("orc_canny_o failed")
     return out
+
+
+def canny_o_stages(img, low=50, high=150, l2gradient=False):
+    """(edges, premap): premap is the map before the flood -- 255 seed, 128 candidate, 0 none."""
+    img = _c8(img)
+    ch = 1 if img.ndim == 2 else img.shape[2]
+    h, w = img.shape[:2]
+    out = np.empty((h, w), np.uint8)
+    pre = np.empty((h, w), np.uint8)
+    rc = lib().orc_canny_o_ex(_p8(img), w * ch, w, h, ch, float(low), float(high), int(bool(l2gradient)), _p8(out), _p8(pre))
+    if rc:
+        raise ValueError("orc_canny_o_ex failed")
+    return out, pre
 
 
 def canny_o_batch(frames, low=50, high=150, l2gradient=False, threads=1):

@@ -31,7 +31,26 @@ int main(int argc, char **argv)
   f = std::fopen(argv[6], "wb");
   if (!f || std::fwrite(out.data(), 1, out.size(), f) != out.size()) return 9;
   std::fclose(f);
-  const double ms = timerManager::Get().getAverageTime(cvp::CANNY_STAGES.at(cvp::HYSTER));
-  std::printf("ok %dx%dx%d stage %d, avg '%s' %.3f ms\n", w, h, ch, stage, cvp::CANNY_STAGES.at(cvp::HYSTER).c_str(), ms);
+  // Per-stage timers (reference: _endCudaTimer(stage) books every stage that ran, src/cvp/cannyEdgeH.cu:415-430, and the
+  // UI sums the rows up to the selected stage, src/imgui/imguiApp.cpp:364-376): after one frame every stage up to
+  // `stage` holds exactly one non-zero sample -- stage 0 only for 3-channel input (1-channel input skips it, unless
+  // MONO itself was asked for) -- and no later stage holds any.
+  if (!pipeline.process(frame, static_cast<cvp::CannyStage>(stage))) return 8;// a second frame: two samples each
+  const auto &timers = timerManager::Get();
+  float sum = 0.0f;
+  bool past = false;
+  for (auto it = timers.beginTimerList(); it != timers.endTimerList(); ++it) {
+    int st = -1;
+    for (const auto &kv : cvp::CANNY_STAGES)
+      if (kv.second == it->first) st = static_cast<int>(kv.first);
+    if (st < 0) return 10;
+    const bool ran = st <= stage && (st != cvp::MONO || ch == 3 || stage == cvp::MONO);
+    std::printf("timer '%s' samples %zu avg %.4f ms%s\n", it->first.c_str(), it->second.nbCount, it->second.averageTime(), ran ? "" : " (not run)");
+    if (ran && (it->second.nbCount != 2 || !(it->second.totalTime > 0.0))) return 11;
+    if (!ran && it->second.nbCount != 0) return 12;
+    if (!past) sum += it->second.averageTime();
+    if (cvp::CANNY_STAGES.at(static_cast<cvp::CannyStage>(stage)) == it->first) past = true;// the UI's partial sum stops here
+  }
+  std::printf("ok %dx%dx%d stage %d, total %.4f ms\n", w, h, ch, stage, sum);
   return 0;
 }

@@ -22,16 +22,23 @@ def test_cpp_surface_builds_and_exports():
     build.build()
     _build()
     syms = subprocess.check_output(["nm", "-DC", "--defined-only", LIB], text=True)
-    for want in ("cvp::cvPipeline::process(cv::Mat, cvp::CannyStage)", "cvp::cvPipeline::setLowThreshold(unsigned char)",
+    # cv::Mat never crosses the boundary (include/cvp/frameView.hpp): the Mat-taking members are inline
+    # wrappers in the headers, the library exports the view forms and no symbol that mentions cv::Mat
+    assert "cv::Mat" not in syms, [l for l in syms.splitlines() if "cv::Mat" in l]
+    for want in ("cvp::cvPipeline::processView(cvp::FrameView const&, cvp::CannyStage)", "cvp::cvPipeline::setLowThreshold(unsigned char)",
                  "cvp::cvPipeline::getHighThreshold() const", "cvp::cvPipeline::enableCudaProfiling(bool)",
-                 "cvp::cvPipeline::isCudaProfilingEnabled() const", "cvp::cuda::CannyEdge::run(cv::Mat, cvp::CannyStage)",
+                 "cvp::cvPipeline::isCudaProfilingEnabled() const", "cvp::cuda::CannyEdge::runView(cvp::FrameView const&, cvp::CannyStage)",
                  "cvp::cuda::CannyEdge::CannyEdge(unsigned int, unsigned int, unsigned int, int)"):
         assert want in syms, want
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("channels,stage", [(1, 5), (3, 5), (1, 3)])
-def test_cpp_pipeline_matches_oracle(oracle, tmp_path, channels, stage):
+@pytest.mark.parametrize("binary", ["test_cvpipeline", "test_cvpipeline_othermat"])
+@pytest.mark.parametrize("channels,stage", [(1, 5), (3, 5), (1, 3), (3, 2), (3, 0), (1, 0), (3, 4)])
+def test_cpp_pipeline_matches_oracle(oracle, tmp_path, channels, stage, binary):
+    """`test_cvpipeline_othermat` is the same driver built against a cv::Mat with OpenCV's member order
+    (tests/cpp/other_mat_layout): the host's Mat layout must not matter to the prebuilt library."""
+    BIN = os.path.join(ROOT, "tests", "cpp", binary)
     if not os.path.exists(BIN):
         _build()
     w, h = 321, 200
@@ -41,5 +48,7 @@ def test_cpp_pipeline_matches_oracle(oracle, tmp_path, channels, stage):
     r = subprocess.run([BIN, str(w), str(h), str(channels), str(fin), str(stage), str(fout)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     got = np.fromfile(fout, np.uint8).reshape(h, w)
-    key = {5: "edges", 3: "nms"}[stage]
+    key = {5: "edges", 4: "thresh", 3: "nms", 2: "grad_disp", 0: "mono"}[stage]
+    if stage == 5 and channels == 3:  # all six timers hold a sample
+        assert r.stdout.count("samples 2") == 6, r.stdout
     assert np.array_equal(got, oracle.canny_r(img, 10, 40, stages=True)[key])

@@ -285,10 +285,28 @@ def test_run_device_unaligned_and_torch_stream(oracle):
     d_in = torch.from_numpy(img).cuda()           # tight pitch 641: not a multiple of 4
     d_out = torch.zeros_like(d_in)
     with api.Context(641, 479, 1, 1) as ctx:
+        # torch's default current stream is the null stream (handle 0): the run is queued on that very stream, behind the
+        # kernels that produced d_in / zeroed d_out
+        assert torch.cuda.current_stream().cuda_stream == 0
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         ctx.run_device(d_in.data_ptr(), 641, 641 * 479, d_out.data_ptr(), 641, 641 * 479, 1)
         ctx.sync()
         _diff(d_out.cpu().numpy(), want, "unaligned run_device")
+        # a side stream of the caller: producer and detector on it, no host synchronisation in between
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            big = torch.from_numpy(np.ascontiguousarray(img[::-1])).cuda(non_blocking=True)
+            d_in2 = big.clone()
+            d_out2 = torch.full_like(d_in2, 7)
+            ctx.set_stream(side.cuda_stream)
+            ctx.run_device(d_in2.data_ptr(), 641, 641 * 479, d_out2.data_ptr(), 641, 641 * 479, 1)
+        ctx.sync()
+        _diff(d_out2.cpu().numpy(), oracle.canny_r(np.ascontiguousarray(img[::-1]), 10, 40), "run_device on a side stream")
+        ctx.use_own_stream()
+        torch.cuda.synchronize()
+        ctx.run_device(d_in.data_ptr(), 641, 641 * 479, d_out.data_ptr(), 641, 641 * 479, 1)
+        ctx.sync()
+        _diff(d_out.cpu().numpy(), want, "own stream again")
 
 
 MODE_O_IMAGES = [
@@ -501,3 +519,24 @@ def test_pipelined_runs_into_one_output_buffer(oracle):
             got = d_out.cpu().numpy()
             for f in range(nb):
                 _diff(got[f], oracle.canny_r(runs[last][f], 10, 40), f"one output buffer, last run {last}, frame {f}")
+
+
+def test_pipelined_one_buffer_with_host_continuation(oracle):
+    """a run whose queued hysteresis launches do not reach the fixpoint is continued from the host when its
+    slot is completed -- after the NEXT run may already have written the same output buffer.  With one queued launch
+    and a serpentine frame the continuation is certain; the buffer must still hold the last run's map."""
+    import torch
+    w, h = 1000, 1100
+    serp = synth.serpentine(w, h)
+    nat = synth.natural(w, h, 77)
+    d_serp, d_nat = torch.from_numpy(serp[None]).cuda(), torch.from_numpy(nat[None]).cuda()
+    d_out = torch.zeros((1, h, w), dtype=torch.uint8, device="cuda")
+    want_nat, want_serp = oracle.canny_r(nat, 10, 40), oracle.canny_r(serp, 10, 40)
+    with api.Context(w, h, 1, 1) as ctx:
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        ctx.set_tuning(0, 1)
+        for order, want in (((d_serp, d_nat), want_nat), ((d_nat, d_serp), want_serp), ((d_serp, d_serp, d_nat), want_nat)):
+            for d in order:
+                ctx.run_device(d.data_ptr(), w, w * h, d_out.data_ptr(), w, w * h, 1)
+            ctx.sync()
+            _diff(d_out.cpu().numpy()[0], want, f"one buffer, {len(order)} runs, continuation")

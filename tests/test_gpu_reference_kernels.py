@@ -18,7 +18,11 @@ u8p, f32p, ip = C.POINTER(C.c_uint8), C.POINTER(C.c_float), C.POINTER(C.c_int)
 def _load(variant):
     path = os.path.join(ROOT, "oracle", "_ref", f"libref_{variant}.so")
     if not os.path.exists(path):
-        pytest.skip(f"{path} not built (oracle/build_ref.sh needs /root/reference)")
+        # the committed fixtures (tests/golden/ref_kernels_*.npz, checked by tests/test_oracle_golden_ref.py on CPU) pin
+        # the same kernels' outputs; with neither the binaries nor the fixtures the oracle would be unpinned: fail
+        gold = os.path.join(ROOT, "tests", "golden", f"ref_kernels_{variant}.npz")
+        assert os.path.exists(gold), f"neither {path} nor {gold} exists: run oracle/build_ref.sh (needs /root/reference)"
+        pytest.skip(f"{path} not built here; its outputs are pinned by {os.path.basename(gold)}")
     from cudacam_amd import api
     api.preload_hip_runtime()  # one HIP runtime per process (see api.preload_hip_runtime)
     L = C.CDLL(path)
@@ -78,19 +82,31 @@ def test_reference_kernels_vs_oracle(oracle, variant, fused, name, make):
     bad = np.argwhere(r["nms"] != nms)
     for (y, x) in bad:  # only direction-boundary pairs may differ (libm atan2 vs exact rule)
         assert _near_boundary(sx[y, x], sy[y, x]), (y, x, int(sx[y, x]), int(sy[y, x]), int(r["nms"][y, x]), int(nms[y, x]))
-    if len(bad) == 0:
-        thr = oracle.threshold(nms, 10, 40)
-        assert np.array_equal(r["thresh"], thr)
-        assert np.array_equal(r["edges"], oracle.hysteresis(thr))
-        assert np.array_equal(r["grad_disp"], oracle.canny_r(img, stages=True)["grad_disp"]) or not fused
-        if fused:  # and the product itself, saturate option on, equals the reference kernels bit for bit
-            from cudacam_amd import api
-            h, w = img.shape
-            with api.Context(w, h, 1, 1) as ctx:
-                ctx.set_option(api.OPT_NMS_SATURATE, 1)
-                for st, key in ((api.CannyStage.GAUSSIAN, "blur"), (api.CannyStage.NMS, "nms"), (api.CannyStage.THRESH, "thresh"),
-                                (api.CannyStage.HYSTER, "edges")):
-                    assert np.array_equal(ctx.process(img, st)[0], r[key]), f"product vs reference kernels: {key}"
+    # later stages from the reference's own NMS plane, so that a direction-boundary pixel cannot hide a difference
+    thr = oracle.threshold(r["nms"], 10, 40)
+    assert np.array_equal(r["thresh"], thr)
+    assert np.array_equal(r["edges"], oracle.hysteresis(thr))
+    assert np.array_equal(r["grad_disp"], oracle.canny_r(img, stages=True)["grad_disp"]) or not fused
+    if fused:  # and the product itself, saturate option on, equals the reference kernels bit for bit
+        from cudacam_amd import api
+        h, w = img.shape
+        ok = np.ones((h, w), bool)
+        for (y, x) in bad:  # a boundary pixel's own NMS value, and whatever the hysteresis grows from it, is excused
+            ok[max(0, y - 1):y + 2, max(0, x - 1):x + 2] = False
+        with api.Context(w, h, 1, 1) as ctx:
+            ctx.set_option(api.OPT_NMS_SATURATE, 1)
+            ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+            for st, key in ((api.CannyStage.GAUSSIAN, "blur"), (api.CannyStage.NMS, "nms"), (api.CannyStage.THRESH, "thresh"),
+                            (api.CannyStage.HYSTER, "edges")):
+                got = ctx.process(img, st)[0]
+                if key in ("blur",) or len(bad) == 0:
+                    assert np.array_equal(got, r[key]), f"product vs reference kernels: {key}"
+                elif key != "edges":
+                    assert np.array_equal(got[ok], r[key][ok]), f"product vs reference kernels: {key} (boundary pixels masked)"
+            # the fast path's own intermediates against the reference kernels' planes
+            assert np.array_equal(ctx.debug_tap(api.TAP_BLUR)[0], r["blur"]), "fast-path blur vs reference gaussianFilter5x5"
+            tt = ctx.debug_tap(api.TAP_THRESH)[0]
+            assert np.array_equal(tt[ok], r["thresh"][ok]), "fast-path bit planes vs reference doubleThreshold"
     assert r["launches"] >= 1
 
 

@@ -1,0 +1,120 @@
+"""The FAST path's own intermediates against the oracle, bit for bit (run on the MI355X box, -m gpu).
+
+test_gpu_parity.py::test_all_stages_mono checks the plain per-stage kernels behind `finalStage` < HYSTER;
+those are not what a HYSTER run executes.  Here the front kernels themselves (k_blur + k_nms, the fused kernel,
+k_front_o) are read back through hc_debug_tap: the blur they computed and the STRONG / CANDIDATE bit planes they
+hand to the hysteresis, compared with oracle.gaussian / oracle.threshold (reference gaussianFilter5x5 and
+doubleThreshold outputs, src/cvp/cannyEdgeD.cu:72-118, 273-293) -- so a wrong blur byte or a wrong candidate bit
+that no strong pixel reaches cannot hide behind the final edge map."""
+import numpy as np
+import pytest
+
+from cudacam_amd import api, synth
+
+from test_gpu_parity import _diff, _images, _nms_queue_patterns
+
+pytestmark = pytest.mark.gpu
+
+FRONT_FORMS = [("split", 1), ("fused", 0)]
+
+
+def _tap_images():
+    yield from _images()
+    for name, img in _nms_queue_patterns():
+        yield "nmsq_" + name, img
+    yield "natural_1000x260", synth.natural(1000, 260, 21)
+    yield "noise_2100x70", synth.noise(2100, 70, 22)          # more than one hysteresis panel wide
+
+
+def _want(oracle, img, low, high, saturate=False):
+    st = oracle.canny_r(img, low, high, stages=True, saturate=saturate)
+    return st["blur"], st["thresh"], st["edges"]
+
+
+@pytest.mark.parametrize("form,split", FRONT_FORMS, ids=[f for f, _ in FRONT_FORMS])
+@pytest.mark.parametrize("name,img", list(_tap_images()), ids=[n for n, _ in _tap_images()])
+def test_front_taps_mono(oracle, name, img, form, split):
+    h, w = img.shape
+    blur, thr, edges = _want(oracle, img, 10, 40)
+    with api.Context(w, h, 1, 1) as ctx:
+        ctx.set_option(api.OPT_FRONT_SPLIT, split)
+        ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+        got = ctx.process(img)[0]
+        _diff(ctx.debug_tap(api.TAP_BLUR)[0], blur, f"{name} {form}: blur of the front kernels")
+        _diff(ctx.debug_tap(api.TAP_THRESH)[0], thr, f"{name} {form}: bit planes of the front kernels")
+        _diff(got, edges, f"{name} {form}: edges")
+
+
+@pytest.mark.parametrize("form,split", FRONT_FORMS, ids=[f for f, _ in FRONT_FORMS])
+@pytest.mark.parametrize("pipeline", [0, 1])
+def test_front_taps_thresholds_and_batch(oracle, form, split, pipeline):
+    """Other thresholds, the saturating NMS variant, a batch, pipelined mode (provisional map on)."""
+    frames = np.stack([synth.natural(520, 300, 31), synth.noise(520, 300, 32), synth.steps(520, 300, 250, "diagonal")])
+    for low, high, sat in ((10, 40, 0), (60, 200, 0), (0, 255, 0), (25, 25, 1)):
+        with api.Context(520, 300, 1, 3) as ctx:
+            ctx.set_thresholds(low, high)
+            ctx.set_option(api.OPT_NMS_SATURATE, sat)
+            ctx.set_option(api.OPT_FRONT_SPLIT, split)
+            ctx.set_option(api.OPT_PIPELINE, pipeline)
+            ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+            got = ctx.process(frames)
+            tb, tt = ctx.debug_tap(api.TAP_BLUR, 3), ctx.debug_tap(api.TAP_THRESH, 3)
+            for f in range(3):
+                blur, thr, edges = _want(oracle, frames[f], low, high, bool(sat))
+                tag = f"frame {f} {form} {low}/{high} sat={sat} pipeline={pipeline}"
+                _diff(tb[f], blur, tag + ": blur")
+                _diff(tt[f], thr, tag + ": bit planes")
+                _diff(got[f], edges, tag + ": edges")
+
+
+@pytest.mark.parametrize("form,split", FRONT_FORMS, ids=[f for f, _ in FRONT_FORMS])
+def test_front_taps_bgr_and_per_channel(oracle, form, split):
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (130, 501, 3), dtype=np.uint8)
+    img[40:90, 100:300] = (200, 30, 90)
+    mono = oracle.gray_bgr(img)
+    blur, thr, edges = _want(oracle, mono, 10, 40)
+    with api.Context(501, 130, 3, 1) as ctx:  # BGR -> grey fused into the front kernel's load
+        ctx.set_option(api.OPT_FRONT_SPLIT, split)
+        ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+        got = ctx.process(img)[0]
+        _diff(ctx.debug_tap(api.TAP_BLUR)[0], blur, f"bgr {form}: blur")
+        _diff(ctx.debug_tap(api.TAP_THRESH)[0], thr, f"bgr {form}: bit planes")
+        _diff(got, edges, f"bgr {form}: edges")
+    with api.Context(501, 130, 3, 1) as ctx:  # one map per channel: output frame 3 f + ch
+        ctx.set_option(api.OPT_PER_CHANNEL, 1)
+        ctx.set_option(api.OPT_FRONT_SPLIT, split)
+        ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+        n = ctx.upload(img)
+        ctx.run(api.CannyStage.HYSTER, n)
+        got = ctx.download(3)
+        tb, tt = ctx.debug_tap(api.TAP_BLUR, 3), ctx.debug_tap(api.TAP_THRESH, 3)
+        for ch in range(3):
+            blur, thr, edges = _want(oracle, np.ascontiguousarray(img[:, :, ch]), 10, 40)
+            _diff(tb[ch], blur, f"channel {ch} {form}: blur")
+            _diff(tt[ch], thr, f"channel {ch} {form}: bit planes")
+            _diff(got[ch], edges, f"channel {ch} {form}: edges")
+
+
+@pytest.mark.parametrize("l2", [0, 1])
+@pytest.mark.parametrize("name,img", list(_images()), ids=[n for n, _ in _images()])
+def test_front_taps_mode_o(oracle, name, img, l2):
+    h, w = img.shape
+    low, high = (50, 150) if not l2 else (40, 120)
+    edges, pre = oracle.canny_o_stages(img, low, high, bool(l2))
+    with api.Context(w, h, 1, 1, mode=api.MODE_O) as ctx:
+        ctx.set_thresholds(low, high)
+        ctx.set_option(api.OPT_L2_GRADIENT, l2)
+        ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+        got = ctx.process(img)[0]
+        _diff(ctx.debug_tap(api.TAP_THRESH)[0], pre, f"{name} mode O l2={l2}: bit planes of k_front_o")
+        _diff(got, edges, f"{name} mode O l2={l2}: edges")
+        with pytest.raises(api.HipCannyError):
+            ctx.debug_tap(api.TAP_BLUR)
+
+
+def test_tap_needs_option():
+    with api.Context(64, 48, 1, 1) as ctx:
+        ctx.process(synth.noise(64, 48, 1))
+        with pytest.raises(api.HipCannyError):
+            ctx.debug_tap(api.TAP_THRESH)
