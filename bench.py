@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--hyst-launches", type=int, default=0, help="hysteresis launches queued per run (0 = auto)")
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
-    ap.add_argument("--fused", action="store_true", help="HC_OPT_FRONT_SPLIT = 0: the single fused front kernel instead of k_blur + k_nms")
+    ap.add_argument("--front", default="front8", choices=["front8", "split", "fused4"], help="Mode R front path (HC_OPT_FRONT_SPLIT): front8 = one kernel, 8 px per lane (default); split = k_blur + k_nms; fused4 = the 4-px fused kernel")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3], help="3: interleaved BGR input (grey conversion fused into the load)")
     ap.add_argument("--per-channel", action="store_true", help="with --channels 3: one edge map per channel (BASELINE configs[4])")
@@ -102,7 +102,7 @@ def main():
     ctx.set_tuning(a.chunk, a.hyst_launches)
     ctx.set_option(api.OPT_PIPELINE, 0 if a.no_pipeline else 1)
     if a.mode == "R":
-        ctx.set_option(api.OPT_FRONT_SPLIT, 0 if a.fused else 1)
+        ctx.set_option(api.OPT_FRONT_SPLIT, {"front8": 2, "split": 1, "fused4": 0}[a.front])
     # the context keeps its own (non-blocking) stream: the inputs were produced before the synchronize below, and the
     # timed region is bracketed by hc_sync + torch.cuda.synchronize, so no ordering with torch's stream is needed
 
@@ -167,7 +167,7 @@ def main():
                        "pipeline": not a.no_pipeline},
             "e2e_alg_GBps": round(alg_bytes_per_frame * frames_total / elapsed / 1e9, 1),
             "roofline": {
-                "bound": "hbm", "kernel": ("k_front" if a.fused else "k_blur+k_nms") if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": {"front8": "k_front8", "split": "k_blur+k_nms", "fused4": "k_front"}[a.front] if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(achieved / HBM_MEASURED_COPY_GBPS, 4),
                 "traffic": None, "kernel_ms": round(front_ms, 4),
                 "kernel_ms_each": ({"k_blur": round(ksums[0] / kruns, 4), "k_nms": round(ksums[1] / kruns, 4)} if kruns else None),

@@ -10,8 +10,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhipcanny.so")
-SOURCES = ["canny_kernels.hip", "hipcanny.hip"]
-DEPS = SOURCES + ["canny_common.h", os.path.join("..", "..", "include", "hipcanny.h")]
+SOURCES = ["canny_kernels.hip", "front8.hip", "hipcanny.hip"]
+DEPS = SOURCES + ["canny_common.h", "canny_device.h", os.path.join("..", "..", "include", "hipcanny.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 

@@ -47,6 +47,8 @@ struct FrontParams {
   uint8_t *prov_out; u32 prov_pitch; size_t prov_fs;
   // diagnostics (HC_OPT_DEBUG_TAPS): the fused kernel also stores its (fixed-up) blur rows here, plain [frame][H][pitch]
   uint8_t *dbg_blur; u32 dbg_pitch; size_t dbg_fs;
+  const uint8_t *zeros;  // k_front8: >= 3 * 8192 + 32 bytes of zeros (what rows above / below the image read as)
+  uint8_t *dump;   // k_front8: >= 16 KiB that may be overwritten with anything (where the branch-free row code stores rows that are not its own)
   u32 wrap_limit;  // S >= wrap_limit: gradient >= 256, the wrap bands apply (0xFFFFFFFF: saturating variant)
 };
 
@@ -83,6 +85,10 @@ hipError_t launch_selftest(u32 *d_result, hipStream_t s);
 hipError_t check_gauss_coeffs(const float gk[25]);
 hipError_t launch_front(const FrontParams &p, hipStream_t s);
 hipError_t launch_front_o(const FrontParams &p, hipStream_t s);
+// front8.hip: the whole front path as one kernel, 8 px per lane (strips of 496 columns, runs of 6 * windows - 4 rows)
+hipError_t launch_front8(const FrontParams &p, hipStream_t s);
+int front8_run_rows(int windows);
+int front8_strips(int W);
 hipError_t launch_blur(const FrontParams &p, hipStream_t s);
 hipError_t launch_nms(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);

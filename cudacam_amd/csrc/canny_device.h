@@ -75,6 +75,21 @@ static __device__ __forceinline__ void wave_lds_sync()
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+// lane in `mask` ? a : b as ONE v_cndmask (written as a select, the compiler may turn it into an exec-masked region,
+// which ends the scheduling region of otherwise straight-line code)
+static __device__ __forceinline__ u32 lane_sel(u64 mask, u32 a, u32 b)
+{
+  u32 d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(mask));
+  return d;
+}
+// wave-uniform cond ? a : b on pointers as two s_cselect (the compiler tends to branch around the address arithmetic of `a`)
+static __device__ __forceinline__ uint8_t *uniform_sel(bool cond, uint8_t *a, uint8_t *b)
+{
+  u64 d;
+  asm("s_cmp_lg_u32 %1, 0\n\ts_cselect_b64 %0, %2, %3" : "=s"(d) : "s"(__builtin_amdgcn_readfirstlane((int)cond)), "s"((u64)a), "s"((u64)b) : "scc");
+  return (uint8_t *)d;
+}
 // tell the compiler a value is wave-uniform (keeps masks and row indices in SGPRs, control flow scalar)
 static __device__ __forceinline__ u64 uniform64(u64 v)
 {

@@ -66,9 +66,10 @@ struct hc_ctx {
   int cur = 0;
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
-  int split = 1;        // front path as k_blur + k_nms (default) or the fused k_front
+  int split = 2;        // Mode R front path: 2 = k_front8 (one kernel, 8 px per lane; default), 1 = k_blur + k_nms, 0 = the 4-px fused k_front
   uintptr_t prev_out0 = 0, prev_out1 = 0;  // output range of the previous pipelined run (provisional-map hazard check)
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
+  uint8_t *d_dump = nullptr;    // k_front8's dump area (FrontParams::dump), followed by its page of zeros (FrontParams::zeros)
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
   size_t bplane_fs = 0, bplane_frames = 0;
   // HC_OPT_DEBUG_TAPS: copies of the bit planes as the front kernels left them, and (fused kernel) a plain blur plane
@@ -379,7 +380,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     fp.subchunks = m; fp.run_rows = front_run_rows(m);
     fp.nstrips = c->nstrips; fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows; fp.nframes = n_out;
     fp.total_items = n_out * fp.nstrips * fp.nchunks;
-    const bool split = c->split && c->mode == HC_MODE_R;
+    // Mode R front path: k_front8 reads whole 8-pixel groups (8 or 24 bytes per lane and row), the 4-px kernels 4-pixel groups
+    const bool can8 = sp >= round_up((size_t)W, 8) * (size_t)(fuse_bgr || c->per_channel ? 3 : 1);
+    const int form = c->mode != HC_MODE_R ? -1 : (c->split == 2 && !can8) ? 1 : c->split;
+    const bool split = form == 1, f8 = form == 2;
     // Pipelined mode: k_nms / k_front_o also write the strong pixels as 255 into the output (4 px per lane: whole
     // dwords need W % 4 == 0), so that the hysteresis, which runs beside the next run's bandwidth-hungry k_blur, only
     // rewrites the 16-pixel groups it changes instead of streaming out the whole map (+8 % end to end; without the
@@ -392,12 +396,12 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     // continuation rewrites whole maps (finish_slot) and would otherwise land on top of this run's result
     if (out_overlap)
       if (int rc = finish_slot(c, c->slot[c->cur ^ 1])) return rc;
-    s.prov = piped && !out_overlap && W % 4 == 0 && (split || c->mode == HC_MODE_O);
+    s.prov = piped && !out_overlap && ((W % 4 == 0 && (split || c->mode == HC_MODE_O)) || (W % 8 == 0 && f8));
     if (piped) { c->prev_out0 = o0; c->prev_out1 = o1; }
     if (s.prov) { fp.prov_out = dst; fp.prov_pitch = (u32)dp; fp.prov_fs = dfs; }
     if (c->debug_taps) {
       if (int rc = ensure_debug_buffers(c)) return rc;
-      if (!split) { fp.dbg_blur = c->dbg_blur; fp.dbg_pitch = (u32)c->out_pitch; fp.dbg_fs = c->out_fs; }
+      if (!split) { fp.dbg_blur = c->dbg_blur; fp.dbg_pitch = (u32)c->out_pitch; fp.dbg_fs = c->out_fs; }  // out_pitch is a multiple of 256
     }
     if (split) {  // k_blur + k_nms through the blur plane
       if (int rc = ensure_blur_plane(c)) return rc;
@@ -410,6 +414,16 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.nchunks_b = (H + rows - 1) / rows;
       fp.total_items_b = n_out * fp.nstrips * fp.nchunks_b;
 
+    }
+    if (f8) {  // strips of 496 columns, runs of 6 * windows - 4 rows
+      fp.dump = c->d_dump;
+      fp.zeros = c->d_dump + 16384;
+      fp.nstrips = front8_strips(W);
+      const int rows = pick_run_rows((long)n_out * fp.nstrips, H, c->chunk);
+      const int windows = std::max(1, (rows + 4 + 5) / 6);
+      fp.run_rows = front8_run_rows(windows);
+      fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
+      fp.total_items = n_out * fp.nstrips * fp.nchunks;
     }
     if (c->mode == HC_MODE_O) {
       // cv::Canny: plain thresholds on the L1 magnitude; long chunks (no LDS slab, 4-row warm-up)
@@ -438,7 +452,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
         HIPCK(launch_nms(fp, sf));
         HIPCK(mark(sf, B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
       } else {
-        HIPCK(launch_front(fp, sf));
+        if (f8) HIPCK(launch_front8(fp, sf));
+        else HIPCK(launch_front(fp, sf));
         HIPCK(mark(sf, b_mono | B_GAUSS | B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
       }
     }
@@ -562,10 +577,11 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     if (sscanf(e, "%dx%d", &tr, &wv) == 2) c->hyst_geom = tr * 100 + wv;
   }
   // (a BGR row is read in 12-byte groups of 4 pixels: keep room for the ragged last group)
-  good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, round_up((size_t)width, 4) * channels, height, max_batch) == HC_OK;
+  good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, round_up((size_t)width, 8) * channels, height, max_batch) == HC_OK;
   good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch) == HC_OK;
   if (good && channels == 3) good = alloc_frames(&c->d_mono, &c->mono_pitch, &c->mono_fs, (size_t)width, height, max_batch) == HC_OK;
   good = good && alloc_slot(c, c->slot[0]) == HC_OK;
+  good = good && ok(hipMalloc((void **)&c->d_dump, 16384 + 32768), "hipMalloc(dump)") && ok(hipMemset(c->d_dump, 0, 16384 + 32768), "hipMemset(dump)");
   c->evpool.assign((size_t)hc_ctx::EV_RUNS * hc_ctx::EV_PER_RUN, nullptr);
   c->runprof.assign((size_t)hc_ctx::EV_RUNS, hc_ctx::RunProf{});
   for (size_t i = 0; good && i < c->evpool.size(); ++i) good = ok(hipEventCreate(&c->evpool[i]), "hipEventCreate");
@@ -586,7 +602,7 @@ void hc_destroy(hc_ctx *c)
   if (!c) return;
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
-  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_bplane }) (void)hipFree(q);
+  for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_bplane, (void *)c->d_dump }) (void)hipFree(q);
   free_slot(c->slot[0]);
   free_slot(c->slot[1]);
   free_debug_buffers(c);
@@ -665,7 +681,8 @@ int hc_set_option(hc_ctx *c, int option, int value)
       if (had1 && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;
     }
   } else if (option == HC_OPT_FRONT_SPLIT) {
-    c->split = value != 0;
+    if (value < 0 || value > 2) return fail(HC_E_ARG, "HC_OPT_FRONT_SPLIT: 0 (k_front), 1 (k_blur + k_nms) or 2 (k_front8)");
+    c->split = value;
   } else if (option == HC_OPT_L2_GRADIENT) {
     if (c->mode != HC_MODE_O) return fail(HC_E_ARG, "HC_OPT_L2_GRADIENT applies to mode O contexts");
     c->l2gradient = value != 0;

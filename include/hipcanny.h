@@ -147,9 +147,11 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * per-channel Canny"): the interleaved input is read once per channel by adjacent work items and
  * every run produces 3 edge maps per input frame, output frame 3*f + ch (ch = byte position in the pixel).
  *
- * HC_OPT_FRONT_SPLIT (default 1, Mode R): 1 = the blur and the Sobel/NMS/threshold halves of the fused
- * path run as two kernels with a u8 blur plane between them (higher occupancy);
- * 0 = one fused kernel (no intermediate in HBM).  Results are identical.
+ * HC_OPT_FRONT_SPLIT (default 2, Mode R): which kernels form the front path (grey | blur | Sobel | NMS | thresholds).
+ * 2 = k_front8: ONE kernel, 8 pixels per lane, no intermediate in HBM (falls back to 1 when an input row does not hold
+ * whole 8-pixel groups, i.e. pitch < round_up(width, 8) * channels); 1 = k_blur + k_nms with a u8 blur plane between
+ * them; 0 = k_front, the earlier 4-pixel fused kernel.  Results are identical; 0 and 1 are kept as independent
+ * implementations for the parity tests.
  *
  * HC_OPT_L2_GRADIENT (default 0, Mode O contexts): cv::Canny's `L2gradient` argument: magnitude dx^2 + dy^2
  * compared with the squared thresholds instead of |dx| + |dy|. */

@@ -56,7 +56,7 @@ def test_all_stages_mono(oracle, name, img):
             _diff(got, want[key], f"{name} stage {stage.name}")
 
 
-@pytest.mark.parametrize("split", [1, 0])
+@pytest.mark.parametrize("split", [2, 1, 0])
 @pytest.mark.parametrize("chunk", [7, 20, 44, 116, 1080])
 def test_chunk_invariance(oracle, chunk, split):
     """Rows per work item (and the one-kernel / two-kernel form of the front path) never change the result."""

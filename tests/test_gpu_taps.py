@@ -15,7 +15,7 @@ from test_gpu_parity import _diff, _images, _nms_queue_patterns
 
 pytestmark = pytest.mark.gpu
 
-FRONT_FORMS = [("split", 1), ("fused", 0)]
+FRONT_FORMS = [("front8", 2), ("split", 1), ("fused4", 0)]
 
 
 def _tap_images():
