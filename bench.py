@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU baseline sample (0 = auto)")
+    ap.add_argument("--sweep", action="store_true", help="one JSON line per batch size in {1, 8, 64, 256, 1024} (SURVEY 8d C2) instead of the single headline line")
+    ap.add_argument("--no-host-fed", action="store_true", help="skip the bounded host-fed (PCIe-inclusive) end-to-end leg")
     return ap.parse_args()
 
 
@@ -66,11 +68,33 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo", rank=rank, world_size=world)
+        backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # the launcher's world must be the one asked for: one rank per GPU, frames sharded over exactly --gpus devices
+        assert dist.get_world_size() == a.gpus == world, f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks"
+    elif a.gpus != 1:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE is 1)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if a.sweep:
+        if world != 1:
+            raise SystemExit("--sweep is a single-GPU measurement")
+        for b in (1, 8, 64, 256, 1024):
+            a.batch = b
+            a.steps_eff = max(a.steps, min(2000, 20480 // b))   # small batches: enough steps for a stable mean
+            run_config(a, torch, dist, world, rank, local, backend, brief=True)
+        return
+    run_config(a, torch, dist, world, rank, local, backend, brief=False)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_config(a, torch, dist, world, rank, local, backend, brief):
+    steps = getattr(a, "steps_eff", a.steps)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -124,7 +148,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(steps):
         step()
     ctx.sync()                      # queues what the pipelined mode still holds back (the last step's hysteresis), waits
                                     # for all of it and verifies the convergence of every step
@@ -133,13 +157,14 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     ksums, kruns = ctx.profile_get_front()
+    intervals = ctx.profile_intervals(steps + 8)
     sums, nruns = ctx.profile_get(reset=True)
     work_launches, continued = ctx.hysteresis_info()
 
     elapsed = shard.reduce_max_seconds(t1 - t0, dist if world > 1 else None, dev)
 
     if rank == 0:
-        frames_total = B * a.steps * world
+        frames_total = B * steps * world
         fps = frames_total / elapsed
         alg_bytes_per_frame = float(W * H * C + W * H * (3 if a.per_channel else 1))   # 2*W*H per mono frame
         alg_bytes_per_launch = alg_bytes_per_frame * B
@@ -151,10 +176,12 @@ def main():
             "value": round(fps, 1),
             "unit": "frames/s",
             "n_gpus": world,
-            "steps": a.steps,
+            "steps": steps,
             "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 4),
-            "ms_per_frame": round(elapsed / (a.steps * B) * 1e3, 6),
+            "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "ms_per_frame": round(elapsed / (steps * B) * 1e3, 6),
+            # per-step times on the device clock: end-of-step to end-of-step hipEvent intervals (rank 0), SURVEY 8d "median and p10/p90"
+            "step_ms": _percentiles(intervals),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -164,7 +191,8 @@ def main():
             "config": {"workload": (f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU" if (W, H, a.mode) == (1920, 1080, "R")
                                     else f"{W}x{H} " + ("grayscale" if C == 1 else "BGR, per-channel Canny" if a.per_channel else "BGR -> grey") + f", mode {a.mode}, batch {B} frames/step/GPU"),
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",
-                       "pipeline": not a.no_pipeline},
+                       "pipeline": not a.no_pipeline, "front": a.front if a.mode == "R" else "k_front_o",
+                       "world_size": world, "backend": backend},
             "e2e_alg_GBps": round(alg_bytes_per_frame * frames_total / elapsed / 1e9, 1),
             "roofline": {
                 "bound": "hbm", "kernel": {"front8": "k_front8", "split": "k_blur+k_nms", "fused4": "k_front"}[a.front] if a.mode == "R" else "k_front_o", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -190,18 +218,75 @@ def main():
                     out["roofline"]["traffic_frac_of_peak"] = round(out["roofline"]["traffic"] / (front_ms * 1e-3) / HBM_PEAK_GBPS, 4) if front_ms > 0 else None
             except (OSError, KeyError, ValueError):
                 pass
-        if not a.no_cpu_baseline and C == 1:
+        if not brief and not a.no_cpu_baseline and C == 1:
             out["cpu_baseline"] = cpu_baseline(a, d_in, d_out)
+        if not brief and not a.no_host_fed and world == 1:
+            out["host_fed"] = host_fed(a, d_in)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+
+
+def _percentiles(ms):
+    if not ms:
+        return None
+    v = np.sort(np.asarray(ms, np.float64))
+    q = lambda f: float(v[min(len(v) - 1, int(f * len(v)))])
+    return {"n": len(v), "median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4), "min": round(float(v[0]), 4), "max": round(float(v[-1]), 4)}
+
+
+def host_fed(a, d_in):
+    """End-to-end with the frames in HOST memory (never `value`): page-locked staging, a ring of three contexts so that
+    batch i uploads while batch i-1 computes and batch i-2 downloads -- the Python twin of cvp::io::FrameStreamer
+    (include/cvp/frameIO.hpp).  Bounded: about a second of work."""
+    import ctypes as C
+    lib = api.load_library()
+    nb = min(16, d_in.shape[0])
+    ch = a.channels
+    frame_in, frame_out = W * H * ch, W * H * (3 if a.per_channel else 1)
+    host_frames = d_in[:nb].cpu().numpy()
+    ring = []
+    for _ in range(3):
+        ctx = api.Context(W, H, ch, nb, api.MODE_R if a.mode == "R" else api.MODE_O)
+        if a.per_channel:
+            ctx.set_option(api.OPT_PER_CHANNEL, 1)
+        ctx.set_thresholds(LOW, HIGH)
+        hin, hout = lib.hc_host_alloc(frame_in * nb), lib.hc_host_alloc(frame_out * nb)
+        C.memmove(hin, host_frames.ctypes.data, frame_in * nb)
+        ring.append((ctx, hin, hout))
+    nbatches = max(6, min(200, int(2.0e9 // (frame_in * nb))))   # ~2 GB through PCIe each way
+    busy = [False] * 3
+
+    def finish(k):
+        ctx, _, hout = ring[k]
+        api._ck(lib.hc_download(ctx.handle, C.c_void_p(hout), W, W * H, nb * (3 if a.per_channel else 1)))
+        busy[k] = False
+
+    t0 = time.perf_counter()
+    for i in range(nbatches):
+        k = i % 3
+        if busy[k]:
+            finish(k)
+        ctx, hin, _ = ring[k]
+        api._ck(lib.hc_upload(ctx.handle, C.c_void_p(hin), W * ch, frame_in, nb))
+        ctx.run(api.CannyStage.HYSTER, nb)
+        busy[k] = True
+    for k in range(3):
+        if busy[(nbatches + k) % 3]:
+            finish((nbatches + k) % 3)
+    dt = time.perf_counter() - t0
+    for ctx, hin, hout in ring:
+        ctx.close()
+        lib.hc_host_free(C.c_void_p(hin))
+        lib.hc_host_free(C.c_void_p(hout))
+    frames = nbatches * nb
+    return {"value": round(frames / dt, 1), "unit": "frames/s", "batch": nb, "batches": nbatches, "contexts": 3, "staging": "page-locked (hc_host_alloc)",
+            "pcie_GBps_each_way": round(frames * frame_in / dt / 1e9, 2), "note": "frames start and end in host memory; one staging thread"}
 
 
 def cpu_baseline(a, d_in, d_out):
-    """The oracle (a CPU port of the reference pipeline, kind "port") timed on the host cores on a
-    bounded sample of the same frames; the GPU output for that sample is checked against it."""
+    """The oracle (a CPU port of the reference pipeline, kind "port") timed on the host cores on a bounded sample of the
+    same frames -- at 1 thread and at all the threads this process may use -- and the GPU output for that sample checked
+    against it; the cv::Canny restatement (Mode O) beside it; and a real OpenCV if this host happens to have one."""
     from oracle import oracle as O   # test infrastructure: only this leg may touch it
     O.build()
     # the GPU box gives one GPU a 16-core CPU share: size the OpenMP pool to it
@@ -211,13 +296,44 @@ def cpu_baseline(a, d_in, d_out):
     sample = d_in[:n].cpu().numpy()
     run = O.canny_r_batch if a.mode == "R" else O.canny_o_batch
     run(sample[:min(n, cores)], LOW, HIGH, threads=cores)   # warm the pages/threads
-    t0 = time.perf_counter()
-    ref = run(sample, LOW, HIGH, threads=cores)
-    dt = time.perf_counter() - t0
+
+    def timed(fn, frames, threads):
+        t0 = time.perf_counter()
+        r = fn(frames, threads)
+        return r, time.perf_counter() - t0
+
+    ref, dt = timed(lambda f, t: run(f, LOW, HIGH, threads=t), sample, cores)
+    n1 = max(2, min(n, 8))
+    _, dt1 = timed(lambda f, t: run(f, LOW, HIGH, threads=t), sample[:n1], 1)
     same = bool(np.array_equal(ref, d_out[:n].cpu().numpy()))
-    return {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of the benchmark's {W}x{H} frames, OpenMP over frames, oracle/canny_oracle.c ({'orc_canny_r' if a.mode == 'R' else 'orc_canny_o'})",
-            "gpu_output_matches": same}
+    other = O.canny_o_batch if a.mode == "R" else O.canny_r_batch
+    olo, ohi = (50, 150) if a.mode == "R" else (10, 40)
+    _, dto = timed(lambda f, t: other(f, olo, ohi, threads=t), sample, cores)
+    out = {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"{n} of the benchmark's {W}x{H} frames, OpenMP over frames, oracle/canny_oracle.c ({'orc_canny_r' if a.mode == 'R' else 'orc_canny_o'})",
+           "gpu_output_matches": same,
+           "one_thread": {"value": round(n1 / dt1, 2), "unit": "frames/s", "cores": 1, "sample": f"{n1} frames"},
+           "other_mode": {"mode": "O (cv::Canny restatement, 50/150)" if a.mode == "R" else "R (reference pipeline, 10/40)", "value": round(n / dto, 2), "unit": "frames/s", "cores": cores},
+           "opencv": opencv_probe(sample, cores)}
+    return out
+
+
+def opencv_probe(sample, cores):
+    """Real cv::Canny on the host cores, if OpenCV is discoverable here (the reference's Conan dependency `opencv`,
+    conanfile.py:22, is not part of this image): timed, and compared with the Mode O restatement bit for bit."""
+    try:
+        import cv2  # noqa: F401
+    except Exception as e:   # ImportError, or a broken binary wheel
+        return {"available": False, "note": f"OpenCV not available on this host ({type(e).__name__}); the Mode O figures are the CPU restatement, not cv::Canny"}
+    from oracle import oracle as O
+    cv2.setNumThreads(cores)
+    t0 = time.perf_counter()
+    maps = [cv2.Canny(f, 50, 150, apertureSize=3, L2gradient=False) for f in sample]
+    dt = time.perf_counter() - t0
+    want = O.canny_o_batch(sample, 50, 150, threads=cores)
+    return {"available": True, "version": cv2.__version__, "value": round(len(sample) / dt, 2), "unit": "frames/s", "threads": cores,
+            "restatement_matches_cv2": bool(all(np.array_equal(m, w) for m, w in zip(maps, want))),
+            "note": "IPP / OpenCL builds of OpenCV may take a different code path than modules/imgproc/src/canny.cpp"}
 
 
 if __name__ == "__main__":

@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
-    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream",
+    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals",
 ]
 
 _lib = None
@@ -113,6 +113,7 @@ def load_library():
     L.hc_set_option.argtypes = [vp, i, i]
     L.hc_selftest.argtypes = [i]
     L.hc_debug_tap.argtypes = [vp, i, vp, sz, sz, i]
+    L.hc_profile_get_intervals.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(i)]
     L.hc_host_alloc.restype = vp
     L.hc_host_alloc.argtypes = [sz]
     L.hc_host_free.restype = None
@@ -192,6 +193,13 @@ class Context:
         n = C.c_long()
         _ck(self.lib.hc_profile_get(self.handle, sums, C.byref(n), int(bool(reset))))
         return [sums[0], sums[1], sums[2]], n.value
+
+    def profile_intervals(self, cap=4096):
+        """End-of-run to end-of-run times (ms) of consecutive profiled runs since the last reset."""
+        buf = (C.c_float * cap)()
+        n = C.c_int()
+        _ck(self.lib.hc_profile_get_intervals(self.handle, buf, cap, C.byref(n)))
+        return [buf[k] for k in range(min(cap, n.value))]
 
     def profile_get_front(self):
         """([k_blur_ms_sum, k_nms_ms_sum], nruns) of the profiled runs that took the split front path; call before

@@ -104,6 +104,8 @@ struct hc_ctx {
   double prof_split_sum[2] = { 0, 0 };  // k_blur, k_nms (split front path only)
   long prof_split_runs = 0;
   long prof_runs = 0;
+  std::vector<float> step_ms;     // end-of-run to end-of-run intervals of consecutive profiled runs (steady-state step time)
+  hipEvent_t prev_end = nullptr;  // last event of the previous profiled run (still valid: the ring is 256 runs deep)
 };
 
 namespace {
@@ -786,6 +788,13 @@ int hc_sync(hc_ctx *c)
       else if (k == hc_ctx::K_FRONT_B && has_a) c->prof_split_sum[1] += t;
     }
     if (has_a) c->prof_split_runs++;
+    if (rp.nint > 0) {
+      if (c->prev_end && c->step_ms.size() < 65536) {
+        float dt = 0;
+        if (hipEventElapsedTime(&dt, c->prev_end, e[rp.nint]) == hipSuccess) c->step_ms.push_back(dt);
+      }
+      c->prev_end = e[rp.nint];
+    }
     c->prof_runs++;
     c->ev_head = (c->ev_head + 1) % hc_ctx::EV_RUNS;
     c->ev_count--;
@@ -819,6 +828,7 @@ int hc_profile_get(hc_ctx *c, double sum_ms[3], long *nruns, int reset)
   if (sum_ms) for (int i = 0; i < 3; ++i) sum_ms[i] = c->prof_sum[i];
   if (nruns) *nruns = c->prof_runs;
   if (reset) {
+    c->step_ms.clear(); c->prev_end = nullptr;
     c->prof_sum[0] = c->prof_sum[1] = c->prof_sum[2] = 0; c->prof_runs = 0;
     c->prof_split_sum[0] = c->prof_split_sum[1] = 0; c->prof_split_runs = 0;
   }
@@ -831,6 +841,16 @@ int hc_profile_get_front(hc_ctx *c, double sum_ms[2], long *nruns)
   if (int rc = hc_sync(c)) return rc;
   if (sum_ms) { sum_ms[0] = c->prof_split_sum[0]; sum_ms[1] = c->prof_split_sum[1]; }
   if (nruns) *nruns = c->prof_split_runs;
+  return HC_OK;
+}
+
+int hc_profile_get_intervals(hc_ctx *c, float *ms, int cap, int *n)
+{
+  if (!c || !n || (cap > 0 && !ms)) return fail(HC_E_ARG, "hc_profile_get_intervals: bad argument");
+  if (int rc = hc_sync(c)) return rc;
+  const int m = (int)std::min<size_t>(c->step_ms.size(), (size_t)std::max(cap, 0));
+  for (int i = 0; i < m; ++i) ms[i] = c->step_ms[(size_t)i];
+  *n = (int)c->step_ms.size();
   return HC_OK;
 }
 

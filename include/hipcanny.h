@@ -112,6 +112,11 @@ int hc_profile_get(hc_ctx *ctx, double sum_ms[3], long *nruns, int reset);
  * sum_ms[0] k_blur, [1] k_nms.  Read it before hc_profile_get(..., reset = 1), which clears both. */
 int hc_profile_get_front(hc_ctx *ctx, double sum_ms[2], long *nruns);
 
+/* Steady-state step times: for every pair of consecutive profiled runs since the last reset, the time from the end of
+ * one run (its last kernel, hysteresis included) to the end of the next, in ms.  In pipelined mode, where runs overlap,
+ * this -- not a run's own start-to-end time -- is what a frame stream sees.  Writes up to `cap` values, *n = how many exist. */
+int hc_profile_get_intervals(hc_ctx *ctx, float *ms, int cap, int *n);
+
 /* Internal device buffers (input frames, output images) and their pitch / frame stride. */
 int hc_device_ptrs(hc_ctx *ctx, void **d_in, void **d_out, size_t *in_pitch, size_t *out_pitch, size_t *in_frame_stride,
                    size_t *out_frame_stride);
