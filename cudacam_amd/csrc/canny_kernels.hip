@@ -1094,7 +1094,9 @@ hipError_t launch_nms(const FrontParams &p, hipStream_t s)
 // axes; strict on both diagonal neighbours), m > high seeds.  Same strip / lane / DPP layout and the same
 // bit-plane output as k_nms, so k_hyst finishes the job.  One pass, registers only (no LDS): a work item is
 // (frame, strip, chunk of p.chunk_rows rows) with a 4-row warm-up.
-template <bool L2>
+// NC: channels of the (interleaved) source.  cv::Canny on a 3-channel image computes the Sobel derivatives of every
+// channel and keeps, per pixel, those of the channel with the largest magnitude -- the first one on ties (canny.cpp).
+template <bool L2, int NC>
 __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
 {
   const int lane = threadIdx.x & 63;
@@ -1125,27 +1127,45 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
   const u32 oknib = oknib1 | (oknib1 << 8);
   const uint8_t *fbase = p.in + (size_t)frame * p.in_frame_stride;  // wave-uniform
   const u32 in_pitch32 = (u32)p.in_pitch;                            // launch_front_o checks H * pitch < 2^32
-  const u32 ld_off = (u32)ld_col;
+  const u32 ld_off = (u32)(NC * ld_col);
   const int rlast = min(H - 1, rend + 1);  // last source row this run needs
-  auto load_row = [&](int row) -> u32 {  // BORDER_REPLICATE along the column: clamp the row; the raw dword (see use_row)
+  struct RawO { u32 d[NC]; };  // the lane's 4 pixels as loaded: 4 bytes, or 12 interleaved ones
+  auto load_row = [&](int row) -> RawO {  // BORDER_REPLICATE along the column: clamp the row; the raw dwords (see use_row)
     const int rr = min(max(row, 0), rlast);
     u32 roff;
     asm("s_mul_i32 %0, %1, %2" : "=s"(roff) : "s"(rr), "s"(in_pitch32));
     u32 o = ld_off;
     asm volatile("" : "+v"(o));  // scalar row base + 32-bit lane offset
-    return *reinterpret_cast<const u32 *>(fbase + roff + o);
+    const u32 *q = reinterpret_cast<const u32 *>(fbase + roff + o);
+    RawO r;
+#pragma unroll
+    for (int i = 0; i < NC; ++i) r.d[i] = q[i];
+    return r;
   };
   // BORDER_REPLICATE along the row: the byte selector, applied when the row is consumed -- applied at the load it
-  // made the wave wait for each request at once
-  auto use_row = [&](u32 raw) -> u32 { return __builtin_amdgcn_perm(0u, raw, rsel); };
+  // made the wave wait for each request at once.  3-channel data: channel ch of the 4 pixels is picked out of the
+  // 12 interleaved bytes first (bytes ch, ch+3, ch+6, ch+9).
+  auto use_row = [&](const RawO &raw, int ch) -> u32 {
+    u32 v = raw.d[0];
+    if constexpr (NC == 3) {
+      const u32 selA = ch == 0 ? 0x0c060300u : ch == 1 ? 0x0c070401u : 0x0c0c0502u;
+      const u32 selB = ch == 0 ? 0x05020100u : ch == 1 ? 0x06020100u : 0x07040100u;
+      v = __builtin_amdgcn_perm(raw.d[NC > 2 ? 2 : 0], __builtin_amdgcn_perm(raw.d[NC > 1 ? 1 : 0], raw.d[0], selA), selB);
+    }
+    return __builtin_amdgcn_perm(0u, v, rsel);
+  };
 
-  u32 dr[2][2], sr[2][2];  // d = x[+1]-x[-1] and s = x[-1]+2x[0]+x[+1] of the two previous rows, [ring][pair]
+  u32 dr[NC][2][2], sr[NC][2][2];  // per channel: d = x[+1]-x[-1] and s = x[-1]+2x[0]+x[+1] of the two previous rows, [ring][pair]
   u32 Mr[3][6];            // magnitude rows: [ring][0]=left neighbour, [1..4]=own 4 px, [5]=right neighbour
   u32 Xr[2][2], Yr[2][2];  // packed dx / dy pairs of the two newest gradient rows
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) dr[a][b] = sr[a][b] = Xr[a][b] = Yr[a][b] = 0;
+    for (int b = 0; b < 2; ++b) {
+      Xr[a][b] = Yr[a][b] = 0;
+#pragma unroll
+      for (int ch = 0; ch < NC; ++ch) dr[ch][a][b] = sr[ch][a][b] = 0;
+    }
 #pragma unroll
   for (int a = 0; a < 3; ++a)
 #pragma unroll
@@ -1160,48 +1180,78 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
   const u32 k_tg22 = 13573u, k_m32768 = 0x8000u;  // 16-bit multiplier operands (low halves): TG22 and -2^15
 
   // one step: source row k arrives -> gradient row k-1 -> NMS / threshold row k-2
-  auto step = [&](auto uc, int k, u32 b) {
+  auto step = [&](auto uc, int k, const RawO &raw) {
     constexpr int u = decltype(uc)::value;
     constexpr int rn = u % 2, rp = (u + 1) % 2;
     constexpr int sN = u % 3, sC = (u + 2) % 3, sU = (u + 1) % 3;
-    const u32 A = unpack_lo(b), B = unpack_hi(b);
-    const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
-    const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
-    u32 dk[2], sk[2];
-    dk[0] = R(I(p1) - I(m1));
-    sk[0] = pk_mad2(A, m1 + p1);
-    dk[1] = R(I(p3) - I(p1));
-    sk[1] = pk_mad2(B, p1 + p3);
     const int i = k - 1;  // gradient row from source rows k-2 (ring rn), k-1 (ring rp), k (new)
     const bool rowbad = i < 0 || i >= H;  // magnitude outside the image is 0
-    u32 Xv[2], Yv[2];
+    u32 Xv[2] = { 0, 0 }, Yv[2] = { 0, 0 };   // dx / dy of the channel kept so far, [pair]
+    u32 Mp[2] = { 0, 0 };                     // L1: its packed magnitudes
+    u32 M4[4] = { 0, 0, 0, 0 };               // L2: its magnitudes, one per pixel
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      Xv[h] = pk_mad2(dr[rp][h], R(I(dr[rn][h]) + I(dk[h]))) & (h == 0 ? pm0 : pm1);  // dx = right - left, smoothed 1-2-1 down the rows
-      Yv[h] = R(I(sk[h]) - I(sr[rn][h])) & (h == 0 ? pm0 : pm1);                       // dy = bottom - top
+    for (int ch = 0; ch < NC; ++ch) {
+      const u32 b = use_row(raw, ch);
+      const u32 A = unpack_lo(b), B = unpack_hi(b);
+      const u32 Bl = from_lane_below(B), Ar = from_lane_above(A);
+      const u32 m1 = pair_shift(A, Bl), p1 = pair_shift(B, A), p3 = pair_shift(Ar, B);
+      u32 dk[2], sk[2];
+      dk[0] = R(I(p1) - I(m1));
+      sk[0] = pk_mad2(A, m1 + p1);
+      dk[1] = R(I(p3) - I(p1));
+      sk[1] = pk_mad2(B, p1 + p3);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const u32 X = pk_mad2(dr[ch][rp][h], R(I(dr[ch][rn][h]) + I(dk[h]))) & (h == 0 ? pm0 : pm1);  // dx = right - left, smoothed 1-2-1 down the rows
+        const u32 Y = R(I(sk[h]) - I(sr[ch][rn][h])) & (h == 0 ? pm0 : pm1);                          // dy = bottom - top
+        dr[ch][rn][h] = dk[h];
+        sr[ch][rn][h] = sk[h];
+        if (L2) {
+          const u32 ma = (u32)mad16<0, 0>(X, X, mul16<0, 0>(Y, Y)), mb = (u32)mad16<1, 1>(X, X, mul16<1, 1>(Y, Y));
+          if (ch == 0) { Xv[h] = X; Yv[h] = Y; M4[2 * h] = ma; M4[2 * h + 1] = mb; }
+          else {  // strictly larger: ties keep the earlier channel
+            const bool ta = ma > M4[2 * h], tb = mb > M4[2 * h + 1];
+            const u32 msk = (ta ? 0x0000FFFFu : 0u) | (tb ? 0xFFFF0000u : 0u);
+            Xv[h] = (X & msk) | (Xv[h] & ~msk);
+            Yv[h] = (Y & msk) | (Yv[h] & ~msk);
+            M4[2 * h] = ta ? ma : M4[2 * h];
+            M4[2 * h + 1] = tb ? mb : M4[2 * h + 1];
+          }
+        } else {  // |dx| + |dy| <= 2040 per half: packed
+          const u32 mp = R(__builtin_elementwise_max(I(X), -I(X))) + R(__builtin_elementwise_max(I(Y), -I(Y)));
+          if (ch == 0) { Xv[h] = X; Yv[h] = Y; Mp[h] = mp; }
+          else {
+            // per half: 0xFFFF where this channel's magnitude is strictly larger (saturating difference, then 0 - min(d, 1))
+            const u16x2 dif = __builtin_elementwise_sub_sat(U(mp), U(Mp[h]));
+            const u16x2 one = { 1, 1 }, zero = { 0, 0 };
+            const u32 msk = R((u16x2)(zero - __builtin_elementwise_min(dif, one)));
+            Xv[h] = (X & msk) | (Xv[h] & ~msk);
+            Yv[h] = (Y & msk) | (Yv[h] & ~msk);
+            Mp[h] = (mp & msk) | (Mp[h] & ~msk);
+          }
+        }
+      }
     }
     if (rowbad) {  // wave-uniform, two rows per frame
       asm volatile("" ::: "memory");  // keeps this one branch instead of per-row selects
       Xv[0] = Xv[1] = Yv[0] = Yv[1] = 0;
+      Mp[0] = Mp[1] = 0;
+      M4[0] = M4[1] = M4[2] = M4[3] = 0;
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const u32 X = Xv[h], Y = Yv[h];
-      Xr[rn][h] = X;
-      Yr[rn][h] = Y;
+      Xr[rn][h] = Xv[h];
+      Yr[rn][h] = Yv[h];
       if (L2) {
-        Mr[sN][1 + 2 * h] = (u32)mad16<0, 0>(X, X, mul16<0, 0>(Y, Y));
-        Mr[sN][2 + 2 * h] = (u32)mad16<1, 1>(X, X, mul16<1, 1>(Y, Y));
-      } else {  // |dx| + |dy| <= 2040 per half: packed, then split
-        const u32 mp = R(__builtin_elementwise_max(I(X), -I(X))) + R(__builtin_elementwise_max(I(Y), -I(Y)));
-        Mr[sN][1 + 2 * h] = mp & 0xFFFFu;
-        Mr[sN][2 + 2 * h] = mp >> 16;
+        Mr[sN][1 + 2 * h] = M4[2 * h];
+        Mr[sN][2 + 2 * h] = M4[2 * h + 1];
+      } else {
+        Mr[sN][1 + 2 * h] = Mp[h] & 0xFFFFu;
+        Mr[sN][2 + 2 * h] = Mp[h] >> 16;
       }
     }
     Mr[sN][0] = from_lane_below(Mr[sN][4]);
     Mr[sN][5] = from_lane_above(Mr[sN][1]);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) { dr[rn][h] = dk[h]; sr[rn][h] = sk[h]; }
 
     const int c = k - 2;
     if (c >= r0 && c < rend) {
@@ -1266,12 +1316,12 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
   // source rows r0-2 .. rend+1, six steps per loop trip (the ring period); a row is requested six steps before it is
   // used and its register refilled at once (unconditional loads: a step waits for the oldest of six, see k_nms)
   const int k0 = r0 - 2, kend = rend + 2;
-  u32 bn[6];
+  RawO bn[6];
 #pragma unroll
   for (int j = 0; j < 6; ++j) bn[j] = load_row(k0 + j);
   auto advance = [&](auto uc, int k) {
     constexpr int j = decltype(uc)::value;
-    const u32 b = use_row(bn[j]);
+    const RawO b = bn[j];
     bn[j] = load_row(k + 6);
     step(uc, k, b);
   };
@@ -1286,12 +1336,19 @@ __global__ __launch_bounds__(256) void k_front_o(const FrontParams p)
   }
 }
 
+// p.bgr != 0: interleaved 3-channel source (rows hold whole 12-byte groups of 4 pixels: pitch >= 3 * round_up(W, 4))
 hipError_t launch_front_o(const FrontParams &p, hipStream_t s)
 {
-  if (p.chunk_rows < 1 || p.bgr || (unsigned long long)p.H * p.in_pitch >= (1ull << 32)) return hipErrorInvalidValue;
+  if (p.chunk_rows < 1 || (unsigned long long)p.H * p.in_pitch >= (1ull << 32)) return hipErrorInvalidValue;
+  if (p.in_pitch < (size_t)(p.bgr ? 3 : 1) * (((size_t)p.W + 3) / 4 * 4)) return hipErrorInvalidValue;
   const dim3 grid((p.total_items + 3) / 4), block(256);
-  if (p.l2gradient) hipLaunchKernelGGL(k_front_o<true>, grid, block, 0, s, p);
-  else hipLaunchKernelGGL(k_front_o<false>, grid, block, 0, s, p);
+  if (p.bgr) {
+    if (p.l2gradient) hipLaunchKernelGGL((k_front_o<true, 3>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_front_o<false, 3>), grid, block, 0, s, p);
+  } else {
+    if (p.l2gradient) hipLaunchKernelGGL((k_front_o<true, 1>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((k_front_o<false, 1>), grid, block, 0, s, p);
+  }
   return hipGetLastError();
 }
 

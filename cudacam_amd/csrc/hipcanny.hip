@@ -301,8 +301,9 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
 
 int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_t *out, size_t out_pitch, size_t out_fs, int n, int stage)
 {
-  if (c->mode == HC_MODE_O && (c->C != 1 || stage != HC_STAGE_HYSTER))
-    return fail(HC_E_ARG, "mode O (cv::Canny) is implemented for 1-channel input and the final edge map only");
+  if (c->mode == HC_MODE_O && stage != HC_STAGE_HYSTER)
+    return fail(HC_E_ARG, "mode O (cv::Canny) produces the final edge map only (cv::Canny has no intermediate outputs)");
+  if (c->mode == HC_MODE_O && c->per_channel) return fail(HC_E_ARG, "HC_OPT_PER_CHANNEL applies to mode R contexts");
   if (c->per_channel && stage != HC_STAGE_HYSTER) return fail(HC_E_ARG, "per-channel mode only produces the final edge maps (HC_STAGE_HYSTER)");
   const int W = c->W, H = c->H;
   const int n_out = c->per_channel ? 3 * n : n;  // output frames (= bit-plane frames)
@@ -320,7 +321,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   // unaligned caller buffers go through the internal pitched ones
   const uint8_t *src = in;
   size_t sp = in_pitch, sfs = in_fs;
-  if (!aligned4(in, in_pitch, in_fs)) {
+  // (mode O on 3-channel data reads whole 12-byte groups of 4 pixels: a tighter caller pitch is staged as well)
+  if (!aligned4(in, in_pitch, in_fs) || (c->mode == HC_MODE_O && c->C == 3 && in_pitch < round_up((size_t)c->W, 4) * 3)) {
     if (int rc = copy_frames_d2d(c, sf, c->d_in, c->in_pitch, c->in_fs, in, in_pitch, in_fs, (size_t)W * c->C, n)) return rc;
     src = c->d_in; sp = c->in_pitch; sfs = c->in_fs;
   }
@@ -440,7 +442,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.chunk_rows = (H + per_strip - 1) / per_strip;
       fp.nchunks = (H + fp.chunk_rows - 1) / fp.chunk_rows;
       fp.total_items = n_out * fp.nstrips * fp.nchunks;
-      if (sp < round_up((size_t)W, 4)) return fail(HC_E_ARG, "mode O needs an input pitch of at least round_up(width, 4)");
+      if (sp < round_up((size_t)W, 4) * (size_t)c->C) return fail(HC_E_ARG, "mode O needs an input pitch of at least round_up(width, 4) * channels");
       HIPCK(launch_front_o(fp, sf));
       HIPCK(mark(sf, B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));  // cv::Canny has no blur stage
     } else {

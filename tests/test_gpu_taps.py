@@ -118,3 +118,49 @@ def test_tap_needs_option():
         ctx.process(synth.noise(64, 48, 1))
         with pytest.raises(api.HipCannyError):
             ctx.debug_tap(api.TAP_THRESH)
+
+
+def _bgr_images():
+    rng = np.random.default_rng(8)
+    yield "noise_333x222", rng.integers(0, 256, (222, 333, 3), dtype=np.uint8)
+    yield "natural3_500x260", np.stack([synth.natural(500, 260, 70 + c) for c in range(3)], axis=-1)
+    a = np.stack([synth.natural(249, 130, 90)] * 3, axis=-1).copy()      # equal channels: every pixel is a tie -> channel 0
+    yield "ties_249x130", a
+    b = np.zeros((64, 96, 3), np.uint8)
+    b[:, 40:, 0] = 200; b[20:, :, 1] = 120; b[:, :, 2] = np.arange(96, dtype=np.uint8)[None, :] * 2   # a different winner per region
+    yield "regions_96x64", b
+    yield "tiny_5x3", rng.integers(0, 256, (3, 5, 3), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("l2", [0, 1])
+@pytest.mark.parametrize("name,img", list(_bgr_images()), ids=[n for n, _ in _bgr_images()])
+def test_mode_o_three_channel(oracle, name, img, l2):
+    """cv::Canny on 3-channel input: per pixel the derivatives of the channel with the largest magnitude, first on ties
+    (oracle: orc_canny_o channels = 3).  Checked before the flood (bit planes) and after it."""
+    h, w = img.shape[:2]
+    low, high = (50, 150) if not l2 else (40, 120)
+    edges, pre = oracle.canny_o_stages(img, low, high, bool(l2))
+    for pipeline in (0, 1):
+        with api.Context(w, h, 3, 2, mode=api.MODE_O) as ctx:
+            ctx.set_thresholds(low, high)
+            ctx.set_option(api.OPT_L2_GRADIENT, l2)
+            ctx.set_option(api.OPT_PIPELINE, pipeline)
+            ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+            got = ctx.process(np.stack([img, img[::-1].copy()]))
+            _diff(ctx.debug_tap(api.TAP_THRESH, 2)[0], pre, f"{name} mode O 3-channel l2={l2}: bit planes of k_front_o")
+            _diff(got[0], edges, f"{name} mode O 3-channel l2={l2} pipeline={pipeline}: edges")
+            _diff(got[1], oracle.canny_o(img[::-1].copy(), low, high, bool(l2)), f"{name} flipped")
+
+
+def test_mode_o_three_channel_device_buffers(oracle):
+    """Tight 3-channel device rows that do not hold whole 12-byte groups are staged through the internal buffer."""
+    import torch
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, (77, 101, 3), dtype=np.uint8)   # pitch 303: not a multiple of 4
+    d_in = torch.from_numpy(img).cuda()
+    d_out = torch.zeros((77, 101), dtype=torch.uint8, device="cuda")
+    with api.Context(101, 77, 3, 1, mode=api.MODE_O) as ctx:
+        torch.cuda.synchronize()
+        ctx.run_device(d_in.data_ptr(), 303, 303 * 77, d_out.data_ptr(), 101, 101 * 77, 1)
+        ctx.sync()
+    _diff(d_out.cpu().numpy(), oracle.canny_o(img, 50, 150), "mode O 3-channel, unaligned device buffers")
