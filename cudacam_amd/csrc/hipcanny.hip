@@ -274,7 +274,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   HystParams hp{};
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags; hp.tflags = s.d_tflags;
   // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
-  hyst_tile_geometry(c->hyst_geom, small_tiles, &hp.tile_rows, &hp.waves);
+  hyst_tile_geometry(c->hyst_geom, small_tiles, (long)n * c->H, &hp.tile_rows, &hp.waves);
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
   hp.npanels = (c->RD + 63) / 64;
   // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
@@ -423,7 +423,14 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.dump = c->d_dump;
       fp.zeros = c->d_dump + 16384;
       fp.nstrips = front8_strips(W);
-      const int rows = pick_run_rows((long)n_out * fp.nstrips, H, c->chunk);
+      // runs of about 16 rounds of the chip for big batches (pick_run_rows); a small batch is cut into short runs instead --
+      // down to 8 rows, where the 8-row warm-up doubles the work but one frame still spreads over 540 waves
+      int rows = pick_run_rows((long)n_out * fp.nstrips, H, c->chunk);
+      if (!c->chunk) {
+        const long units = (long)n_out * fp.nstrips;
+        const long want = 3072;  // resident waves of this kernel
+        if (units * ((H + rows - 1) / rows) < want) rows = std::max(8, (int)(H / std::max<long>(1, (want + units - 1) / units)));
+      }
       const int windows = std::max(1, (rows + 4 + 5) / 6);
       fp.run_rows = front8_run_rows(windows);
       fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
@@ -753,6 +760,7 @@ int hc_hysteresis_device(hc_ctx *c, const void *d_thresh, size_t in_pitch, size_
   size_t dp = out_pitch, dfs = out_fs;
   const bool out_internal = !aligned4(d_out, out_pitch, out_fs);
   if (out_internal) { dst = c->d_out; dp = c->out_pitch; dfs = c->out_fs; }
+  s.prov = false;  // nothing has written a provisional map into this output (a pipelined run may have left the flag set)
   if (int rc = queue_hyst_expand(c, s, c->stream, dst, dp, dfs, n, false)) return rc;
   if (out_internal) {
     if (int rc = copy_frames_d2d(c, c->stream, d_out, out_pitch, out_fs, c->d_out, c->out_pitch, c->out_fs, (size_t)c->W, n)) return rc;
