@@ -344,25 +344,42 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
       d[r][0] = R(I(A) - I(Pm)); d[r][1] = R(I(B) - I(A)); d[r][2] = R(I(Cq) - I(B));
       s[r][0] = pk_mad2(c0p, Pm + A); s[r][1] = pk_mad2(c1p, A + B); s[r][2] = pk_mad2(c2p, B + Cq);
     }
-    // zero padding of the Sobel / gradient stages (cannyEdgeD.cu:142-149, 222-229): columns and rows outside the image
-    u32 pm[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const u32 vlo = (u32)(col0 + 2 * j - 1) < (u32)W ? 0x0000FFFFu : 0u, vhi = (u32)(col0 + 2 * j) < (u32)W ? 0xFFFF0000u : 0u;
-      pm[j] = vlo | vhi;
-    }
-    const u32 mU = row > 0 ? 0xFFFFFFFFu : 0u, mN = row + 1 < H ? 0xFFFFFFFFu : 0u;
+    // zero padding of the Sobel / gradient stages (cannyEdgeD.cu:142-149, 222-229): the sums of columns and rows outside
+    // the image are zero.  Only half-lanes at the frame's border see any -- one batch in many has such an entry at all,
+    // so the masks are built and applied in a variant of their own (wave-uniform choice)
     u32 SU[6], SC[6], SN[6], Xc[3], Yc[3];
+    auto sums = [&](auto masked) {
+      constexpr bool MASKED = decltype(masked)::value;
+      u32 pm[3] = { ~0u, ~0u, ~0u }, mU = ~0u, mN = ~0u;
+      if constexpr (MASKED) {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const u32 XU = pk_mad2(d[1][j], R(I(d[0][j]) + I(d[2][j]))) & (pm[j] & mU), YU = R(I(s[0][j]) - I(s[2][j])) & (pm[j] & mU);
-      const u32 XC = pk_mad2(d[2][j], R(I(d[1][j]) + I(d[3][j]))) & pm[j], YC = R(I(s[1][j]) - I(s[3][j])) & pm[j];
-      const u32 XN = pk_mad2(d[3][j], R(I(d[2][j]) + I(d[4][j]))) & (pm[j] & mN), YN = R(I(s[2][j]) - I(s[4][j])) & (pm[j] & mN);
-      SU[2 * j] = (u32)mad16<0, 0>(XU, XU, mul16<0, 0>(YU, YU)); SU[2 * j + 1] = (u32)mad16<1, 1>(XU, XU, mul16<1, 1>(YU, YU));
-      SC[2 * j] = (u32)mad16<0, 0>(XC, XC, mul16<0, 0>(YC, YC)); SC[2 * j + 1] = (u32)mad16<1, 1>(XC, XC, mul16<1, 1>(YC, YC));
-      SN[2 * j] = (u32)mad16<0, 0>(XN, XN, mul16<0, 0>(YN, YN)); SN[2 * j + 1] = (u32)mad16<1, 1>(XN, XN, mul16<1, 1>(YN, YN));
-      Xc[j] = XC; Yc[j] = YC;
-    }
+        for (int j = 0; j < 3; ++j) {
+          const u32 vlo = (u32)(col0 + 2 * j - 1) < (u32)W ? 0x0000FFFFu : 0u, vhi = (u32)(col0 + 2 * j) < (u32)W ? 0xFFFF0000u : 0u;
+          pm[j] = vlo | vhi;
+        }
+        mU = row > 0 ? 0xFFFFFFFFu : 0u;
+        mN = row + 1 < H ? 0xFFFFFFFFu : 0u;
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        u32 XU = pk_mad2(d[1][j], R(I(d[0][j]) + I(d[2][j]))), YU = R(I(s[0][j]) - I(s[2][j]));
+        u32 XC = pk_mad2(d[2][j], R(I(d[1][j]) + I(d[3][j]))), YC = R(I(s[1][j]) - I(s[3][j]));
+        u32 XN = pk_mad2(d[3][j], R(I(d[2][j]) + I(d[4][j]))), YN = R(I(s[2][j]) - I(s[4][j]));
+        if constexpr (MASKED) {
+          XU &= pm[j] & mU; YU &= pm[j] & mU;
+          XC &= pm[j]; YC &= pm[j];
+          XN &= pm[j] & mN; YN &= pm[j] & mN;
+        }
+        SU[2 * j] = (u32)mad16<0, 0>(XU, XU, mul16<0, 0>(YU, YU)); SU[2 * j + 1] = (u32)mad16<1, 1>(XU, XU, mul16<1, 1>(YU, YU));
+        SC[2 * j] = (u32)mad16<0, 0>(XC, XC, mul16<0, 0>(YC, YC)); SC[2 * j + 1] = (u32)mad16<1, 1>(XC, XC, mul16<1, 1>(YC, YC));
+        SN[2 * j] = (u32)mad16<0, 0>(XN, XN, mul16<0, 0>(YN, YN)); SN[2 * j + 1] = (u32)mad16<1, 1>(XN, XN, mul16<1, 1>(YN, YN));
+        Xc[j] = XC; Yc[j] = YC;
+      }
+    };
+    // (an entry's pixels -1 .. 4 are columns col0-1 .. col0+4; its rows row-1 .. row+1)
+    const bool at_border = live && (col0 == 0 || col0 + 4 >= W || row == 0 || row + 1 >= H);
+    if (__ballot(at_border) != 0) sums(std::true_type{});
+    else sums(std::false_type{});
     // S*[0] / [5]: the neighbouring pixels -1 / 4; S*[1 + q]: the half's own pixel q
     const u32 gmax = max(max(SC[1], SC[2]), max(SC[3], SC[4]));
     const bool wraps = __ballot(live && gmax >= wrap_limit) != 0;

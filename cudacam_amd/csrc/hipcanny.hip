@@ -425,11 +425,17 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.nstrips = front8_strips(W);
       // runs of about 16 rounds of the chip for big batches (pick_run_rows); a small batch is cut into short runs instead --
       // down to 8 rows, where the 8-row warm-up doubles the work but one frame still spreads over 540 waves
-      int rows = pick_run_rows((long)n_out * fp.nstrips, H, c->chunk);
-      if (!c->chunk) {
+      // Run length.  Every run repeats an 8-row warm-up, so long runs are cheaper -- measured optimum 110-180 rows at 1024
+      // frames, provided the runs tile the frame evenly (a last run of a few rows pays the warm-up for nothing): the frame
+      // is cut into round(H / 120) equal runs.  A small batch is cut into shorter runs instead, down to 8 rows, where the
+      // warm-up doubles the work but one frame still spreads over 540 waves (3072 waves of this kernel are resident).
+      int rows;
+      if (c->chunk) rows = std::min(std::max(c->chunk, 2), H);
+      else {
         const long units = (long)n_out * fp.nstrips;
-        const long want = 3072;  // resident waves of this kernel
-        if (units * ((H + rows - 1) / rows) < want) rows = std::max(8, (int)(H / std::max<long>(1, (want + units - 1) / units)));
+        long nch = std::max<long>(1, (H + 60) / 120);
+        if (units * nch < 3072) nch = std::min<long>((3072 + units - 1) / units, std::max(1, H / 8));
+        rows = (int)((H + nch - 1) / nch);
       }
       const int windows = std::max(1, (rows + 4 + 5) / 6);
       fp.run_rows = front8_run_rows(windows);
