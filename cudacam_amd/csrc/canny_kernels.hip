@@ -1507,7 +1507,10 @@ struct HystGeom { int nw, tr, waves; };
 // launches.  4 waves x 32 rows (one wave per SIMD) when it runs beside the next run's front kernels (pipelined mode):
 // a 4-wave workgroup finds a place as soon as one wave slot per SIMD frees up, an 8-wave one has to wait for two --
 // measured 1.7 ms against 4.2 ms for the hysteresis of 1024 frames under overlap.
-static inline HystGeom hyst_geom(bool beside_front) { return beside_front ? HystGeom{ 1, 32, 4 } : HystGeom{ 1, 32, 8 }; }
+// (beside k_front8, whose three workgroups fill a CU's LDS and registers, a hysteresis workgroup only finds room when a
+// front workgroup retires: 2-wave workgroups fit the freed wave slots best -- 376 k frames/s against 368 k with 4 waves,
+// 350 k with 8; one-wave workgroups need more launches than are queued for a 1080-row frame)
+static inline HystGeom hyst_geom(bool beside_front) { return beside_front ? HystGeom{ 1, 32, 2 } : HystGeom{ 1, 32, 8 }; }
 // frames_x_rows: frames x rows of the run.  geom: 0 = by the rules here; otherwise a shape picked by the caller for tuning experiments (encoded rows * 100 + waves:
 // 3208, 3204, 3202, 1608, 3216 -- hc_create reads HC_HYST_GEOM once)
 void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int *tile_rows, int *waves)
@@ -1517,7 +1520,7 @@ void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int *ti
   // latency -- 8 waves x 16 rows per workgroup halve the rows a wave walks one after the other (measured on one 1080p
   // frame: hysteresis 0.122 ms against 0.139 ms with 8 x 32 and 0.130 ms with 4 x 32)
   if (frames_x_rows < 128 * 1024) g = HystGeom{ 1, 16, 8 };
-  if (geom == 3208 || geom == 3204 || geom == 3202 || geom == 1608 || geom == 3216) g = HystGeom{ 1, geom / 100, geom % 100 };
+  if (geom == 3208 || geom == 3204 || geom == 3202 || geom == 1608 || geom == 3216 || geom == 3201 || geom == 1604 || geom == 1602) g = HystGeom{ 1, geom / 100, geom % 100 };
   *tile_rows = g.tr;
   *waves = g.waves;
 }
@@ -1908,6 +1911,9 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   else if (g.nw == 1 && g.tr == 32 && g.waves == 2) HC_HYST_LAUNCH(32, 2)
   else if (g.nw == 1 && g.tr == 16 && g.waves == 8) HC_HYST_LAUNCH(16, 8)
   else if (g.nw == 1 && g.tr == 32 && g.waves == 16) HC_HYST_LAUNCH(32, 16)
+  else if (g.nw == 1 && g.tr == 32 && g.waves == 1) HC_HYST_LAUNCH(32, 1)
+  else if (g.nw == 1 && g.tr == 16 && g.waves == 4) HC_HYST_LAUNCH(16, 4)
+  else if (g.nw == 1 && g.tr == 16 && g.waves == 2) HC_HYST_LAUNCH(16, 2)
 #undef HC_HYST_LAUNCH
   else return hipErrorInvalidValue;
   return hipGetLastError();
