@@ -5,6 +5,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 static int fails = 0;
 #define CHECK(c) do { if (!(c)) { std::printf("FAIL line %d: %s\n", __LINE__, #c); ++fails; } } while (0)
@@ -57,6 +58,41 @@ int main(int argc, char **argv)
     CHECK(!cvp::io::readPNM(dir + "/does_not_exist.pgm", m));
     cv::Mat c3(2, 2, CV_8UC3);
     CHECK(!cvp::io::writePGM(dir + "/t_c3.pgm", c3));
+  }
+  // PNG: grey and B,G,R round trips through the writer (zlib deflate, filter None), pitched source
+  {
+    std::uint8_t buf[7 * 12];
+    for (int i = 0; i < 84; ++i) buf[i] = static_cast<std::uint8_t>(i * 11 + 3);
+    cv::Mat g(7, 9, CV_8UC1, buf, 12);
+    CHECK(cvp::io::writePNG(dir + "/t_grey.png", g));
+    cv::Mat back;
+    CHECK(cvp::io::readImage(dir + "/t_grey.png", back));
+    CHECK(back.rows == 7 && back.cols == 9 && back.channels() == 1);
+    for (int r = 0; r < 7; ++r) CHECK(std::memcmp(back.ptr(r), g.ptr(r), 9) == 0);
+    cv::Mat c(2, 4, CV_8UC3, buf, 12);
+    CHECK(cvp::io::writePNG(dir + "/t_bgr.png", c));
+    cv::Mat cb;
+    CHECK(cvp::io::readImage(dir + "/t_bgr.png", cb));
+    CHECK(cb.rows == 2 && cb.cols == 4 && cb.channels() == 3);
+    for (int r = 0; r < 2; ++r) CHECK(std::memcmp(cb.ptr(r), c.ptr(r), 12) == 0);
+    // readImage tells PNM from PNG by content, not by name
+    CHECK(cvp::io::readImage(dir + "/t_grey.pgm", back) && back.cols == 6);
+    // a corrupted chunk (CRC) and a truncated file are refused
+    std::FILE *f = std::fopen((dir + "/t_grey.png").c_str(), "rb");
+    std::vector<unsigned char> bytes(4096);
+    const std::size_t n = std::fread(bytes.data(), 1, bytes.size(), f);
+    std::fclose(f);
+    bytes.resize(n);
+    std::vector<unsigned char> bad = bytes;
+    bad[n / 2] ^= 0x40;
+    f = std::fopen((dir + "/t_badcrc.png").c_str(), "wb");
+    std::fwrite(bad.data(), 1, bad.size(), f);
+    std::fclose(f);
+    CHECK(!cvp::io::readImage(dir + "/t_badcrc.png", back));
+    f = std::fopen((dir + "/t_trunc.png").c_str(), "wb");
+    std::fwrite(bytes.data(), 1, n - 20, f);
+    std::fclose(f);
+    CHECK(!cvp::io::readImage(dir + "/t_trunc.png", back));
   }
   std::printf(fails ? "test_frameio: %d failure(s)\n" : "test_frameio: ok\n", fails);
   return fails ? 1 : 0;

@@ -1,4 +1,4 @@
-// canny_files -- headless front end of the detector: binary PGM / PPM files in, <name>.edges.pgm out.
+// canny_files -- headless front end of the detector: PNG or binary PGM / PPM files in, <name>.edges.pgm out.
 //   canny_files [-o outdir] [--low L] [--high H] [--batch N] [--repeat R] [--threads T] [--no-write] file...
 // All files must have the same size and channel count.  Frames are streamed through cvp::io::FrameStreamer
 // (page-locked staging, upload / compute / download overlapped); prints the end-to-end rate, disk excluded
@@ -33,12 +33,12 @@ int main(int argc, char **argv)
     else files.push_back(a);
   }
   if (files.empty()) {
-    std::fprintf(stderr, "usage: canny_files [-o outdir] [--low L] [--high H] [--batch N] [--repeat R] [--threads T] [--no-write] file.pgm|file.ppm ...\n");
+    std::fprintf(stderr, "usage: canny_files [-o outdir] [--low L] [--high H] [--batch N] [--repeat R] [--threads T] [--no-write] file.png|file.pgm|file.ppm ...\n");
     return 2;
   }
   std::vector<cv::Mat> frames(files.size());
   for (std::size_t i = 0; i < files.size(); ++i)
-    if (!cvp::io::readPNM(files[i], frames[i])) {
+    if (!cvp::io::readImage(files[i], frames[i])) {
       std::fprintf(stderr, "cannot read %s (binary P5/P6 with maxval 255 expected)\n", files[i].c_str());
       return 1;
     }
