@@ -1685,6 +1685,34 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   // change.  Waves exchange their boundary rows through LDS between rounds.
   u64 changed = 0;
   u32 colchg = 0;  // bit 0: first column of the panel changed, bit 1: last column
+  // First launch, full wave tile: instead of visiting every row once to find out that most have nothing to do (a
+  // worklist step costs ~55 instructions even then, more than half of them scalar), the rows that can change at all
+  // are found first, all at once: a row is active iff one of its open candidates has a strong 8-neighbour -- in the
+  // rows above / below as they are now, or in the row itself.  32 independent tests with compile-time row registers
+  // (no s_set_gpr_idx, no dependency between them); every other row is only visited if a neighbour changes later.
+  // (Two unrolled sequential sweeps with compile-time registers were tried instead: 63 inlined row updates are 76 KB of
+  // code, the instruction cache misses made the hysteresis 1.9x slower.)
+  if (NW == 1 && p.iter == 0 && n == TR) {
+    u64 act = 0;
+    auto test_row = [&](auto self, auto rc) {
+      constexpr int r = decltype(rc)::value;
+      RowBits<NW> nbr;
+      const u32 upv = r == 0 ? up_src[lane] : sr[0][r > 0 ? r - 1 : 0];
+      const u32 dnv = r == TR - 1 ? dn_src[lane] : sr[0][r < TR - 1 ? r + 1 : 0];
+      const u32 sv = sr[0][r], cv = cr[0][r];
+      nbr.w[0] = upv | dnv | sv;
+      RowBits<NW> d = row_dilate<NW>(nbr);
+      if (PANELS) {
+        if (((lmask >> r) & 7ull) != 0 && lane == 0) d.w[0] |= 1u;
+        if (((rmask >> r) & 7ull) != 0 && lane == 63) d.w[NW - 1] |= 0x80000000u;
+      }
+      if (__ballot((cv & ~sv & d.w[0]) != 0) != 0) act |= 1ull << r;
+      if constexpr (r + 1 < TR) self(self, std::integral_constant<int, r + 1>{});
+    };
+    test_row(test_row, std::integral_constant<int, 0>{});
+    dirty = uniform64(act);
+    unfilled = dirty;  // (only) the active rows may still need their first in-row fill: in every other row no open candidate touches a strong bit of the row
+  }
   for (int round = 0; round < 4096; ++round) {
     u64 round_changed = 0;
     while (dirty) {
