@@ -95,7 +95,7 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
 size_t front_lds_bytes();
 int front_run_rows(int subchunks);
-void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int *tile_rows, int *waves);
+void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, int *tile_rows, int *waves);
 
 // plain per-stage kernels (exact, unfused): the `finalStage` taps MONO..THRESH of CannyEdge::run
 hipError_t launch_gray(const uint8_t *bgr, size_t bpitch, size_t bfs, uint8_t *mono, size_t mpitch, size_t mfs, int W, int H, int n, hipStream_t s);

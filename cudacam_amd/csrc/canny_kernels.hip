@@ -1513,9 +1513,14 @@ struct HystGeom { int nw, tr, waves; };
 static inline HystGeom hyst_geom(bool beside_front) { return beside_front ? HystGeom{ 1, 32, 2 } : HystGeom{ 1, 32, 8 }; }
 // frames_x_rows: frames x rows of the run.  geom: 0 = by the rules here; otherwise a shape picked by the caller for tuning experiments (encoded rows * 100 + waves:
 // 3208, 3204, 3202, 1608, 3216 -- hc_create reads HC_HYST_GEOM once)
-void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int *tile_rows, int *waves)
+void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, int *tile_rows, int *waves)
 {
   HystGeom g = hyst_geom(beside_front);
+  // taller frames, taller tiles: an edge that runs down the frame crosses a tile boundary per launch, and only 16 launches
+  // are queued per run (about 17 row tiles per frame at every size: 4K 97.3 k against 95.2 k frames/s, 8K x 3 channels
+  // 6.4 k against 5.1 k, where the 2-wave tiles needed a host-side continuation every step)
+  if (beside_front && H > 2400) g.waves = 8;
+  else if (beside_front && H > 1200) g.waves = 4;
   // a few frames only (the reference's one-frame-per-call pattern): the chip is nearly empty and the launches are pure
   // latency -- 8 waves x 16 rows per workgroup halve the rows a wave walks one after the other (measured on one 1080p
   // frame: hysteresis 0.122 ms against 0.139 ms with 8 x 32 and 0.130 ms with 4 x 32)

@@ -92,10 +92,13 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   u32 *fq = reinterpret_cast<u32 *>(bring + F8_RING * F8_ROW_BYTES);
   lds_u32 *nq = (lds_u32 *)(fq + F8_FQ + 4);
 
-  int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
-  if (item >= p.total_items) return;
-  // per-channel mode: the three channels of one (frame, strip, run) are adjacent work items -- the same workgroup or the
-  // next one on the same XCD -- so the interleaved input is fetched from HBM once and served to the other two from cache
+  // Mono / BGR: 4 independent waves per workgroup.  Per-channel mode: a workgroup is the THREE channels of one (frame,
+  // strip, run), a wave each, kept within one window of each other by a barrier per window -- so the 24 interleaved bytes
+  // per lane and row are fetched from HBM once and served to the other two waves from the CU's L1 / the XCD's L2.
+  // (Without the barrier the three drifted apart and the input was fetched about twice: 5.5 GB per 16 8K frames.)
+  constexpr int WPB = IN == 2 ? 3 : 4;
+  int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPB + wib);
+  if (item >= p.total_items) return;  // (per-channel: total_items is a multiple of 3, a workgroup leaves as a whole)
   int ch = 0;
   if (IN == 2) { ch = item % 3; item /= 3; }
   const int chunk = item % p.nchunks;
@@ -527,6 +530,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
     while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
     wave_lds_sync();  // the next window's phase 1 overwrites the oldest ring rows
+    if (IN == 2) __syncthreads();  // the three channels of this run stay within a window of each other (see above)
     bslot0 = bslot0 + F8_SUB >= F8_RING ? bslot0 + F8_SUB - F8_RING : bslot0 + F8_SUB;
   }
 }
@@ -534,9 +538,12 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
 template <int IN>
 static hipError_t launch_front8_t(const FrontParams &p, hipStream_t s)
 {
-  const dim3 grid((unsigned)((p.total_items + 3) / 4)), block(256);
-  if (p.prov_out) hipLaunchKernelGGL((k_front8<IN, true>), grid, block, front8_lds_bytes(), s, p);
-  else hipLaunchKernelGGL((k_front8<IN, false>), grid, block, front8_lds_bytes(), s, p);
+  constexpr int WPB = IN == 2 ? 3 : 4;
+  if (IN == 2 && p.total_items % 3 != 0) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((p.total_items + WPB - 1) / WPB)), block(64 * WPB);
+  const size_t lds = (size_t)WPB * F8_WAVE_BYTES;
+  if (p.prov_out) hipLaunchKernelGGL((k_front8<IN, true>), grid, block, lds, s, p);
+  else hipLaunchKernelGGL((k_front8<IN, false>), grid, block, lds, s, p);
   return hipGetLastError();
 }
 

@@ -274,7 +274,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   HystParams hp{};
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags; hp.tflags = s.d_tflags;
   // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
-  hyst_tile_geometry(c->hyst_geom, small_tiles, (long)n * c->H, &hp.tile_rows, &hp.waves);
+  hyst_tile_geometry(c->hyst_geom, small_tiles, (long)n * c->H, c->H, &hp.tile_rows, &hp.waves);
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
   hp.npanels = (c->RD + 63) / 64;
   // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
