@@ -102,8 +102,10 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     f0, f1 = shard.frame_range(B * world, rank, world)   # this rank's block of every step's frame stream
     assert f1 - f0 == B
     C = a.channels
-    if C == 3 and (a.mode != "R" or W % 4):
-        raise SystemExit("--channels 3 needs mode R and a width that is a multiple of 4 (whole 12-byte pixel groups)")
+    if C == 3 and W % 4:
+        raise SystemExit("--channels 3 needs a width that is a multiple of 4 (whole 12-byte pixel groups in a tight row)")
+    if a.per_channel and a.mode != "R":
+        raise SystemExit("--per-channel is a mode R option")
     nu = min(a.unique, B)
     if C == 1:
         uniq = synth.frames(a.kind, W, H, nu, seed=synth.SEED0 + 1000 * rank)

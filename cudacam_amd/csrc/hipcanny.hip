@@ -28,8 +28,8 @@ int fail(int code, const std::string &msg)
   } while (0)
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-constexpr int MAX_HYST_LAUNCHES = 16;
-constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0..15] launch flags, [16..63] 3 diagnostic words per launch
+constexpr int MAX_HYST_LAUNCHES = 48;
+constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0 .. MAX) launch flags, then 3 diagnostic words per launch
 
 // Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's
 // hysteresis (pipelined mode); the plain mode only uses slot 0.
@@ -86,7 +86,8 @@ struct hc_ctx {
   int hyst_geom = 0;
   bool hyst_launches_set = false;  // hc_set_tuning called: queue exactly that many launches
   int last_work_launches = 0, last_continued = 0;
-  u32 h_stats[3 * 16] = { 0 };
+  int hyst_need_rows = 0;  // launches that found work in recent runs (continuation rounds included) x rows per tile: how far changes travelled
+  u32 h_stats[3 * MAX_HYST_LAUNCHES] = { 0 };
   int uploaded = 0, last_run_n = 0;
   bool profiling = false;
   // hipEvent ring: up to EV_PER_RUN events per profiled run.  Interval i = ev[i] -> ev[i + 1] covers the reference stages
@@ -237,6 +238,8 @@ int finish_slot(hc_ctx *c, Slot &s)
   std::memcpy(c->h_stats, s.h_flags + MAX_HYST_LAUNCHES, sizeof(c->h_stats));
   c->last_work_launches = std::min(K, work + 1);
   c->last_continued = 0;
+  const int tile = s.ph.tile_rows * s.ph.waves;
+  c->hyst_need_rows = std::max(c->last_work_launches * tile, c->hyst_need_rows - 32);  // follows the content up at once, down slowly
   if (s.h_flags[K - 1] == 0) return HC_OK;
   c->last_continued = 1;
   for (int round = 0; round < 1000000; ++round) {
@@ -253,6 +256,7 @@ int finish_slot(hc_ctx *c, Slot &s)
     for (int k = 0; k < K; ++k) c->last_work_launches += s.h_flags[k] != 0;
     if (s.h_flags[K - 1] == 0) break;
   }
+  c->hyst_need_rows = std::max(c->hyst_need_rows, c->last_work_launches * tile);
   if (s.copy_dst)
     if (int rc = copy_frames_d2d(c, st, s.copy_dst, s.copy_pitch, s.copy_fs, s.ph.out, s.ph.out_pitch, s.ph.out_frame_stride, (size_t)c->W, s.n)) return rc;
   HIPCK(hipStreamSynchronize(st));
@@ -275,11 +279,20 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags; hp.tflags = s.d_tflags;
   // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
   hyst_tile_geometry(c->hyst_geom, small_tiles, (long)n * c->H, c->H, &hp.tile_rows, &hp.waves);
+  // Adaptive: a launch carries a change across one tile boundary, so frames whose weak edges wind through many tiles need
+  // many launches (three natural images blended into one grey frame: 56 with 64-row tiles).  The next runs use tiles
+  // tall enough for about 20 launches, and queue as many launches as the last ones needed, + 2 -- a stream of similar
+  // frames stops needing the host-side continuation (which stalls the pipeline) after its first step.
+  while (hp.waves < 8 && c->hyst_need_rows > 20 * hp.tile_rows * hp.waves) hp.waves *= 2;
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
   hp.npanels = (c->RD + 63) / 64;
   // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
   // tall frame (later launches exit at once after convergence; beyond the queue, hc_sync continues from the host)
-  const int K = c->hyst_launches_set ? c->hyst_launches : std::min(MAX_HYST_LAUNCHES, std::max(c->hyst_launches, hp.nrtiles + hp.npanels));
+  // (one more than the tiles an edge can cross monotonically: the last queued launch must find nothing to do, or the host
+  // continues in hc_sync -- which stalls a pipelined stream of runs)
+  const int need = (c->hyst_need_rows + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
+  const int K = c->hyst_launches_set ? c->hyst_launches
+                                     : std::min(MAX_HYST_LAUNCHES, std::max(std::max(c->hyst_launches, hp.nrtiles + hp.npanels + 1), need + 2));
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
   hp.prov = s.prov ? 1 : 0;
@@ -667,7 +680,7 @@ int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
 {
   if (!c) return fail(HC_E_ARG, "null context");
   if (chunk_rows < 0 || chunk_rows > 16384) return fail(HC_E_ARG, "chunk_rows must be 0 (auto) or 1..16384");
-  if (hyst_launches < 0 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range (0 = auto, 1..16)");
+  if (hyst_launches < 0 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range (0 = auto, 1..48)");
   if (int rc = finish_all(c)) return rc;
   c->chunk = chunk_rows;
   c->hyst_launches_set = hyst_launches != 0;

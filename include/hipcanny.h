@@ -129,8 +129,8 @@ int hc_last_hysteresis_info(hc_ctx *ctx, int *launches_with_work, int *continued
 int hc_hysteresis_stats(hc_ctx *ctx, unsigned *stats, int nwords);
 
 /* Tuning knobs: rows per front-path work item (0 = auto); hysteresis launches queued per run (0 = auto:
- * 6, or one per row tile for tall frames, at most 16; launches after convergence exit at once, and hc_sync
- * continues from the host in the rare case the queue was too short). */
+ * 6, or one more than the row tiles + column panels of a frame, at most 48; launches after convergence exit at once, and
+ * hc_sync continues from the host in the rare case the queue was too short -- non-monotone, serpentine edges). */
 int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
 
 /* Options.  HC_OPT_NMS_SATURATE (default 0): the reference stores `min((unsigned char)gradVal, 255)`
