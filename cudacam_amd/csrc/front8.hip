@@ -293,16 +293,19 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     // overwritten later by this same wave (stores of one wave to one address keep their order).  Rows that are not ours
     // go to a dump area.
     {
-      uint8_t *sp = uniform_sel(valid, splane + (u32)c * plane_pitch, p.dump), *cp = uniform_sel(valid, cplane + (u32)c * plane_pitch, p.dump + 2048);
+      // (typed as global pointers: from the opaque select the compiler would otherwise build 64-bit flat addresses per lane)
+      typedef __attribute__((address_space(1))) uint8_t gmem_u8;
+      typedef __attribute__((address_space(1))) g_u32x2 gmem_u32x2;
+      gmem_u8 *sp = (gmem_u8 *)uniform_sel(valid, splane + (u32)c * plane_pitch, p.dump), *cp = (gmem_u8 *)uniform_sel(valid, cplane + (u32)c * plane_pitch, p.dump + 2048);
       u32 so = st_off;
       asm volatile("" : "+v"(so));
       sp[so] = 0;
       cp[so] = 0;
       if constexpr (PROV) {
-        uint8_t *pp = uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump + 4096);
+        gmem_u8 *pp = (gmem_u8 *)uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump + 4096);
         u32 o = prov_voff;
         asm volatile("" : "+v"(o));
-        *reinterpret_cast<g_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
+        *reinterpret_cast<gmem_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
       }
     }
     // ids of the candidate half-lanes: a lane's two halves share an output byte -- if both are queued they sit in
