@@ -9,8 +9,12 @@
  * vectors for this path (its test/ directory only tests a Factorial placeholder).  The oracle is
  * pinned instead by (i) the known-answer values recorded in SURVEY.md App. C.4 (tests/golden/
  * survey_kat.json), (ii) exhaustive domain checks of every integer shortcut against the literal
- * float formulas of the reference (tests/test_oracle_exhaustive.py) and (iii) on the GPU box, the
- * reference's own device kernels compiled in place by oracle/build_ref.sh (oracle/_ref/).
+ * float formulas of the reference (tests/test_oracle_exhaustive.py), (iii) on the GPU box, the
+ * reference's own device kernels compiled in place by oracle/build_ref.sh (oracle/_ref/) and (iv) the
+ * committed outputs of those kernels for 17 cases, every stage (tests/golden/ref_kernels_*.npz, checked on
+ * CPU by tests/test_oracle_golden_ref.py).  Those kernels are the reference's source compiled by hipcc, not
+ * nvcc, and launched by a restatement of the reference's host code: see DESIGN.md section 5 for what that
+ * does and does not pin.
  *
  * "Mode R" = reference-exact (src/cvp/cannyEdgeD.cu).  "Mode O" = OpenCV cv::Canny restatement.
  * All images are tightly described by (pointer, row stride in elements, width, height).
