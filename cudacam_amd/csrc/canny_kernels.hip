@@ -1829,12 +1829,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
         for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
       }
     };
-    u32 *xq = xqueue + wib * XQ_CAP;  // ring of changed groups: bits | row << 16 | group-of-the-panel-row << 21
+    u32 *xq = xqueue + wib * XQ_CAP;  // ring of changed groups: bits | row (6 bits) << 16 | group-of-the-panel-row << 22
     int xhead = 0, xcount = 0;
     auto xflush = [&](int nent) {
       wave_lds_sync();
       const u32 ent = xq[(xhead + lane) & (XQ_CAP - 1)];
-      if (lane < nent) put16(ent & 0xFFFFu, b0 + w0 + (int)((ent >> 16) & 31u), pcol * 32 + (int)(ent >> 21) * 16);
+      if (lane < nent) put16(ent & 0xFFFFu, b0 + w0 + (int)((ent >> 16) & 63u), pcol * 32 + (int)(ent >> 22) * 16);
       xhead = (xhead + nent) & (XQ_CAP - 1);
       xcount -= nent;
     };
@@ -1903,8 +1903,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
           asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nlo) : "s"(mlo) : "scc");
           asm("s_bcnt1_i32_b64 %0, %1" : "=s"(nhi) : "s"(mhi) : "scc");
           const u32 base = (u32)(xhead + xcount), tag = (u32)r << 16;
-          if (clo) xq[(base + mbcnt64(mlo)) & (XQ_CAP - 1)] = (rowv & 0xFFFFu) | tag | ((u32)(2 * lane) << 21);
-          if (chi) xq[(base + nlo + mbcnt64(mhi)) & (XQ_CAP - 1)] = (rowv >> 16) | tag | ((u32)(2 * lane + 1) << 21);
+          if (clo) xq[(base + mbcnt64(mlo)) & (XQ_CAP - 1)] = (rowv & 0xFFFFu) | tag | ((u32)(2 * lane) << 22);
+          if (chi) xq[(base + nlo + mbcnt64(mhi)) & (XQ_CAP - 1)] = (rowv >> 16) | tag | ((u32)(2 * lane + 1) << 22);
           xcount += (int)(nlo + nhi);
         }
       }
@@ -1947,6 +1947,7 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   else if (g.nw == 1 && g.tr == 32 && g.waves == 1) HC_HYST_LAUNCH(32, 1)
   else if (g.nw == 1 && g.tr == 16 && g.waves == 4) HC_HYST_LAUNCH(16, 4)
   else if (g.nw == 1 && g.tr == 16 && g.waves == 2) HC_HYST_LAUNCH(16, 2)
+
 #undef HC_HYST_LAUNCH
   else return hipErrorInvalidValue;
   return hipGetLastError();
