@@ -33,12 +33,17 @@ for i in range(cases):
     frames = np.stack([np.roll(img, 3 * k, axis=1) for k in range(nb)])
     opts = {}
     if mode == "R":
-        opts["sat"] = int(rng.integers(0, 2)); opts["split"] = int(rng.integers(0, 2)); opts["chunk"] = int(rng.choice([0, 2, 9, 24, 50, 400]))
+        opts["sat"] = int(rng.integers(0, 2)); opts["split"] = int(rng.choice([2, 2, 2, 1, 0])); opts["chunk"] = int(rng.choice([0, 2, 8, 9, 24, 50, 122, 400]))   # split: 2 k_front8, 1 k_blur + k_nms, 0 k_front
         want = np.stack([O.canny_r(f, low, high, saturate=bool(opts["sat"])) for f in frames])
     else:
         opts["l2"] = int(rng.integers(0, 2))
         want = np.stack([O.canny_o(f, low, high, l2gradient=bool(opts["l2"])) for f in frames])
     ch = 1
+    if mode == "O" and rng.random() < 0.3:   # cv::Canny on 3-channel input: per pixel the channel with the largest magnitude
+        ch = 3
+        frames = np.stack([np.stack([np.roll(f, 5 * c, axis=0) ^ np.uint8(29 * c) for c in range(3)], axis=-1) for f in frames])
+        opts["pc"] = 0
+        want = np.stack([O.canny_o(f, low, high, l2gradient=bool(opts["l2"])) for f in frames])
     if mode == "R" and rng.random() < 0.3:   # interleaved 3-channel input: grey conversion (fused or fallback) or per-channel maps
         ch = 3
         frames = np.stack([np.stack([np.roll(f, 5 * c, axis=0) ^ np.uint8(17 * c) for c in range(3)], axis=-1) for f in frames])
@@ -55,9 +60,21 @@ for i in range(cases):
             ctx.set_option(api.OPT_NMS_SATURATE, opts["sat"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)
         else:
             ctx.set_option(api.OPT_L2_GRADIENT, opts["l2"])
+        taps = mode == "R" and rng.random() < 0.3
+        if taps:
+            ctx.set_option(api.OPT_DEBUG_TAPS, 1)
         n_in = ctx.upload(frames)
         ctx.run(api.CannyStage.HYSTER, n_in)
         got = ctx.download(len(want))
+        if taps:   # the fast path's own blur and bit planes, stage by stage
+            tb, tt = ctx.debug_tap(api.TAP_BLUR, len(want)), ctx.debug_tap(api.TAP_THRESH, len(want))
+            planes = [np.ascontiguousarray(f[:, :, c]) for f in frames for c in range(3)] if ch == 3 and opts["pc"] else [O.gray_bgr(f) for f in frames] if ch == 3 else list(frames)
+            for k, pl in enumerate(planes):
+                st = O.canny_r(pl, low, high, stages=True, saturate=bool(opts["sat"]))
+                if not (np.array_equal(tb[k], st["blur"]) and np.array_equal(tt[k], st["thresh"])):
+                    bad += 1
+                    print(f"MISMATCH (fast-path taps, map {k}) case {i}: {w}x{h} {kind} seed {seed} thr {low}/{high} nb {nb} ch {ch} {opts}", flush=True)
+                    break
     if ch == 1 and rng.random() < 0.35:
         # the same case once more through the pipelined device path: three runs in a row (the frames rolled
         # differently each time) into two output buffers used in turn; the last two maps are checked
