@@ -205,12 +205,12 @@ namespace io
     return readPNMRaw(path, pixels, width, height, channels);
   }
 
-  FrameStreamer::FrameStreamer(int width, int height, int channels, int batch, int depth, int device)
+  FrameStreamer::FrameStreamer(int width, int height, int channels, int batch, int depth, int device, int mode)
     : m_w(width), m_h(height), m_c(channels), m_batch(batch), m_slots(static_cast<std::size_t>(depth < 2 ? 2 : depth))
   {
     const std::size_t inBytes = static_cast<std::size_t>(m_w) * m_c * m_h * m_batch, outBytes = static_cast<std::size_t>(m_w) * m_h * m_batch;
     for (Slot &s : m_slots) {
-      s.ctx = hc_create(device, m_w, m_h, m_c, m_batch, HC_MODE_R);
+      s.ctx = hc_create(device, m_w, m_h, m_c, m_batch, mode == 1 ? HC_MODE_O : HC_MODE_R);
       if (!s.ctx) die("hc_create");
       s.hostIn = static_cast<std::uint8_t *>(hc_host_alloc(inBytes));
       s.hostOut = static_cast<std::uint8_t *>(hc_host_alloc(outBytes));

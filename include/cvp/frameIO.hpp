@@ -83,7 +83,8 @@ namespace io
     // edges: `n` tight width x height u8 maps (0 / 255); firstIndex: running index of the first frame of the batch
     using Sink = std::function<void(const std::uint8_t *edges, int n, long firstIndex)>;
 
-    FrameStreamer(int width, int height, int channels, int batch, int depth = 3, int device = 0);
+    // mode: 0 = the reference's pipeline (HC_MODE_R), 1 = cv::Canny semantics (HC_MODE_O)
+    FrameStreamer(int width, int height, int channels, int batch, int depth = 3, int device = 0, int mode = 0);
     ~FrameStreamer();
     FrameStreamer(const FrameStreamer &) = delete;
     FrameStreamer &operator=(const FrameStreamer &) = delete;

@@ -132,3 +132,19 @@ def test_streamed_files_match_oracle(oracle, tmp_path, channels, batch):
     for i in range(n):
         got = _read_pgm(str(tmp_path / f"f{i:02d}.edges.pgm"))
         assert np.array_equal(got, oracle.canny_r(frames[i], 10, 40)), f"frame {i}"
+
+
+@pytest.mark.gpu
+def test_baseline_config0_png_640x480_mode_o(oracle, tmp_path):
+    """BASELINE configs[0]: a single 640x480 grayscale PNG through cv::Canny -- here the PNG goes through the headless
+    front end in Mode O (cv::Canny semantics) and Mode R; the maps equal the CPU restatement / the oracle.  (A real OpenCV
+    is probed by bench.py's cpu_baseline leg; this image has none.)"""
+    _make()
+    img = synth.natural(640, 480, 640480)
+    (tmp_path / "frame.png").write_bytes(_png_bytes(img, [4, 2, 1, 0, 3]))
+    out = subprocess.run([CLI, "-o", str(tmp_path), "--mode", "O", "--batch", "1", str(tmp_path / "frame.png")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert np.array_equal(_read_pgm(str(tmp_path / "frame.edges.pgm")), oracle.canny_o(img, 50, 150))
+    out = subprocess.run([CLI, "-o", str(tmp_path), "--batch", "1", str(tmp_path / "frame.png")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert np.array_equal(_read_pgm(str(tmp_path / "frame.edges.pgm")), oracle.canny_r(img, 10, 40))

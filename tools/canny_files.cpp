@@ -1,5 +1,6 @@
 // canny_files -- headless front end of the detector: PNG or binary PGM / PPM files in, <name>.edges.pgm out.
-//   canny_files [-o outdir] [--low L] [--high H] [--batch N] [--repeat R] [--threads T] [--no-write] file...
+//   canny_files [-o outdir] [--mode R|O] [--low L] [--high H] [--batch N] [--repeat R] [--threads T] [--no-write] file...
+// --mode O: cv::Canny(img, low, high, 3, false) semantics instead of the reference's pipeline (defaults 50 / 150).
 // All files must have the same size and channel count.  Frames are streamed through cvp::io::FrameStreamer
 // (page-locked staging, upload / compute / download overlapped); prints the end-to-end rate, disk excluded
 // when --repeat re-streams the already loaded frames.
@@ -17,13 +18,14 @@
 int main(int argc, char **argv)
 {
   std::string outdir = ".";
-  int low = 10, high = 40, batch = 16, repeat = 1, threads = 4;
+  int low = -1, high = -1, batch = 16, repeat = 1, threads = 4, mode = 0;
   bool nowrite = false;  // rate measurements: stream, but leave the disk out
   std::vector<std::string> files;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     auto next = [&](int &v) { if (i + 1 < argc) v = std::atoi(argv[++i]); };
     if (a == "-o" && i + 1 < argc) outdir = argv[++i];
+    else if (a == "--mode" && i + 1 < argc) mode = (argv[++i][0] == 'O' || argv[i][0] == 'o') ? 1 : 0;
     else if (a == "--low") next(low);
     else if (a == "--high") next(high);
     else if (a == "--batch") next(batch);
@@ -33,7 +35,7 @@ int main(int argc, char **argv)
     else files.push_back(a);
   }
   if (files.empty()) {
-    std::fprintf(stderr, "usage: canny_files [-o outdir] [--low L] [--high H] [--batch N] [--repeat R] [--threads T] [--no-write] file.png|file.pgm|file.ppm ...\n");
+    std::fprintf(stderr, "usage: canny_files [-o outdir] [--mode R|O] [--low L] [--high H] [--batch N] [--repeat R] [--threads T] [--no-write] file.png|file.pgm|file.ppm ...\n");
     return 2;
   }
   std::vector<cv::Mat> frames(files.size());
@@ -49,7 +51,9 @@ int main(int argc, char **argv)
       return 1;
     }
   if (batch < 1) batch = 1;
-  cvp::io::FrameStreamer streamer(w, h, ch, batch);
+  if (low < 0) low = mode ? 50 : 10;
+  if (high < 0) high = mode ? 150 : 40;
+  cvp::io::FrameStreamer streamer(w, h, ch, batch, 3, 0, mode);
   streamer.setThresholds(low, high);
   const std::size_t frameBytes = static_cast<std::size_t>(w) * ch * h;
   long written = 0;
