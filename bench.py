@@ -220,7 +220,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
                     out["roofline"]["traffic_frac_of_peak"] = round(out["roofline"]["traffic"] / (front_ms * 1e-3) / HBM_PEAK_GBPS, 4) if front_ms > 0 else None
             except (OSError, KeyError, ValueError):
                 pass
-        if not brief and not a.no_cpu_baseline and C == 1:
+        if not brief and not a.no_cpu_baseline and C == 1 and world == 1:   # the CPU baseline is an N = 1 figure
             out["cpu_baseline"] = cpu_baseline(a, d_in, d_out)
         if not brief and not a.no_host_fed and world == 1:
             out["host_fed"] = host_fed(a, d_in)

@@ -291,8 +291,12 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // (one more than the tiles an edge can cross monotonically: the last queued launch must find nothing to do, or the host
   // continues in hc_sync -- which stalls a pipelined stream of runs)
   const int need = (c->hyst_need_rows + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
-  const int K = c->hyst_launches_set ? c->hyst_launches
-                                     : std::min(MAX_HYST_LAUNCHES, std::max(std::max(c->hyst_launches, hp.nrtiles + hp.npanels + 1), need + 2));
+  int K = std::min(MAX_HYST_LAUNCHES, std::max(std::max(c->hyst_launches, hp.nrtiles + hp.npanels + 1), need + 2));
+  // One or a few frames per call, not pipelined (the reference's pattern): every queued launch that finds nothing to do
+  // still costs ~5 us of pure latency, so only what the last runs needed is queued, + 2; frames that need more are
+  // finished by the host-side continuation (cheap here: nothing else is in flight).
+  if (!small_tiles && (long)n * c->H < 128 * 1024 && c->hyst_need_rows > 0) K = std::min(K, std::max(4, need + 2));
+  if (c->hyst_launches_set) K = c->hyst_launches;
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
   hp.prov = s.prov ? 1 : 0;
