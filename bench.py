@@ -37,7 +37,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=100, help="timed steps (0.3 s of GPU time at the default batch; the pipelined mode exposes one hysteresis tail per run of steps)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU (2 GiB in + 2 GiB out at 1080p; hysteresis is latency-bound, larger batches amortise it)")
-    ap.add_argument("--unique", type=int, default=8, help="distinct synthetic frames (tiled to the batch)")
+    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to the batch; about 0.7 s of host time each at 1080p)")
     ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--hyst-launches", type=int, default=0, help="hysteresis launches queued per run (0 = auto)")
@@ -162,6 +162,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     intervals = ctx.profile_intervals(steps + 8)
     sums, nruns = ctx.profile_get(reset=True)
     work_launches, continued = ctx.hysteresis_info()
+    in_staged, out_staged, front_form = ctx.last_run_info()
 
     elapsed = shard.reduce_max_seconds(t1 - t0, dist if world > 1 else None, dev)
 
@@ -204,6 +205,8 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
                 "hyst_expand_ms": round(hyst_ms, 4), "launches_timed": nruns,
             },
             "hysteresis": {"launches_with_work": work_launches, "continued": continued},
+            # the caller's buffers were used in place (no hidden staging copies) and the front path that actually ran
+            "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form)},
         }
         # HBM bytes per launch of the front kernels from the committed PMC passes (separate rocprofv3 runs of this
         # command, tools/collect_profiles.sh); only quoted when that profile was taken on this very configuration

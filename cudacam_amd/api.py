@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
-    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals",
+    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals", "hc_last_run_info",
 ]
 
 _lib = None
@@ -113,6 +113,7 @@ def load_library():
     L.hc_set_option.argtypes = [vp, i, i]
     L.hc_selftest.argtypes = [i]
     L.hc_debug_tap.argtypes = [vp, i, vp, sz, sz, i]
+    L.hc_last_run_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.hc_profile_get_intervals.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(i)]
     L.hc_host_alloc.restype = vp
     L.hc_host_alloc.argtypes = [sz]
@@ -241,6 +242,12 @@ class Context:
     def hysteresis_device(self, d_thr, in_pitch, in_fs, d_out, out_pitch, out_fs, nframes):
         _ck(self.lib.hc_hysteresis_device(self.handle, C.c_void_p(d_thr), in_pitch, in_fs, C.c_void_p(d_out), out_pitch,
                                           out_fs, int(nframes)))
+
+    def last_run_info(self):
+        """(input_staged, output_staged, front_form) of the last run: see hc_last_run_info."""
+        a, b, f = C.c_int(), C.c_int(), C.c_int()
+        _ck(self.lib.hc_last_run_info(self.handle, C.byref(a), C.byref(b), C.byref(f)))
+        return bool(a.value), bool(b.value), f.value
 
     def hysteresis_info(self):
         a, b = C.c_int(), C.c_int()

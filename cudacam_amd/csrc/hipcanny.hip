@@ -86,6 +86,7 @@ struct hc_ctx {
   int hyst_geom = 0;
   bool hyst_launches_set = false;  // hc_set_tuning called: queue exactly that many launches
   int last_work_launches = 0, last_continued = 0;
+  int last_in_staged = 0, last_out_staged = 0, last_front_form = -1;  // what the last run did with the caller's buffers / which front kernels it used
   int hyst_need_rows = 0;  // launches that found work in recent runs (continuation rounds included) x rows per tile: how far changes travelled
   u32 h_stats[3 * MAX_HYST_LAUNCHES] = { 0 };
   int uploaded = 0, last_run_n = 0;
@@ -339,7 +340,9 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   const uint8_t *src = in;
   size_t sp = in_pitch, sfs = in_fs;
   // (mode O on 3-channel data reads whole 12-byte groups of 4 pixels: a tighter caller pitch is staged as well)
+  c->last_in_staged = 0;
   if (!aligned4(in, in_pitch, in_fs) || (c->mode == HC_MODE_O && c->C == 3 && in_pitch < round_up((size_t)c->W, 4) * 3)) {
+    c->last_in_staged = 1;
     if (int rc = copy_frames_d2d(c, sf, c->d_in, c->in_pitch, c->in_fs, in, in_pitch, in_fs, (size_t)W * c->C, n)) return rc;
     src = c->d_in; sp = c->in_pitch; sfs = c->in_fs;
   }
@@ -347,6 +350,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   size_t dp = out_pitch, dfs = out_fs;
   const bool out_internal = !aligned4(out, out_pitch, out_fs);
   if (out_internal) { dst = c->d_out; dp = c->out_pitch; dfs = c->out_fs; }
+  c->last_out_staged = out_internal ? 1 : 0;
+  c->last_front_form = -1;
 
   const bool prof = c->profiling && c->ev_count < hc_ctx::EV_RUNS;  // ring full: this run goes untimed
   hipEvent_t *ev = nullptr;
@@ -405,6 +410,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     const bool can8 = sp >= round_up((size_t)W, 8) * (size_t)(fuse_bgr || c->per_channel ? 3 : 1);
     const int form = c->mode != HC_MODE_R ? -1 : (c->split == 2 && !can8) ? 1 : c->split;
     const bool split = form == 1, f8 = form == 2;
+    c->last_front_form = form;
     // Pipelined mode: k_nms / k_front_o also write the strong pixels as 255 into the output (4 px per lane: whole
     // dwords need W % 4 == 0), so that the hysteresis, which runs beside the next run's bandwidth-hungry k_blur, only
     // rewrites the 16-pixel groups it changes instead of streaming out the whole map (+8 % end to end; without the
@@ -943,6 +949,15 @@ int hc_debug_tap(hc_ctx *c, int what, uint8_t *host, size_t row_stride, size_t f
     for (int f = 0; f < n; ++f)
       HIPCK(hipMemcpy2D(host + frame_stride * f, row_stride, c->dbg_blur + c->out_fs * f, c->out_pitch, (size_t)W, (size_t)H, hipMemcpyDeviceToHost));
   }
+  return HC_OK;
+}
+
+int hc_last_run_info(hc_ctx *c, int *input_staged, int *output_staged, int *front_form)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (input_staged) *input_staged = c->last_in_staged;
+  if (output_staged) *output_staged = c->last_out_staged;
+  if (front_form) *front_form = c->last_front_form;
   return HC_OK;
 }
 

@@ -124,6 +124,13 @@ int hc_device_ptrs(hc_ctx *ctx, void **d_in, void **d_out, size_t *in_pitch, siz
 /* Number of hysteresis launches that did work in the last run, and whether the continuation ran. */
 int hc_last_hysteresis_info(hc_ctx *ctx, int *launches_with_work, int *continued);
 
+/* What the last hc_run / hc_run_device did with the caller's buffers -- no silent cliffs: *input_staged / *output_staged are
+ * 1 when the frames went through the context's internal pitched buffers (an extra device-to-device copy each: pointer,
+ * pitch or frame stride not a multiple of 4, or 3-channel mode O rows without whole 12-byte groups), and *front_form is
+ * the front path that ran (HC_OPT_FRONT_SPLIT value 2 / 1 / 0; -1 for mode O and for final stages below HYSTER): a
+ * context set to k_front8 falls back to k_blur + k_nms when a row does not hold whole 8-pixel groups. */
+int hc_last_run_info(hc_ctx *ctx, int *input_staged, int *output_staged, int *front_form);
+
 /* Diagnostics of the last run's queued hysteresis launches: 3 words per launch
  * (sweeps summed over tiles, max sweeps of a tile, tiles that did work). */
 int hc_hysteresis_stats(hc_ctx *ctx, unsigned *stats, int nwords);

@@ -292,6 +292,7 @@ def test_run_device_unaligned_and_torch_stream(oracle):
         ctx.run_device(d_in.data_ptr(), 641, 641 * 479, d_out.data_ptr(), 641, 641 * 479, 1)
         ctx.sync()
         _diff(d_out.cpu().numpy(), want, "unaligned run_device")
+        assert ctx.last_run_info() == (True, True, 2)   # both buffers went through the internal pitched ones: reported, not hidden
         # a side stream of the caller: producer and detector on it, no host synchronisation in between
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
@@ -540,3 +541,31 @@ def test_pipelined_one_buffer_with_host_continuation(oracle):
                 ctx.run_device(d.data_ptr(), w, w * h, d_out.data_ptr(), w, w * h, 1)
             ctx.sync()
             _diff(d_out.cpu().numpy()[0], want, f"one buffer, {len(order)} runs, continuation")
+
+
+def test_last_run_info_reports_form_and_staging(oracle):
+    """Aligned caller buffers are used in place by k_front8; a row that does not hold whole 8-pixel groups falls back to
+    k_blur + k_nms (and says so); mode O reports no Mode R front form."""
+    import torch
+    img = synth.natural(640, 100, 3)
+    d_in = torch.from_numpy(img).cuda()
+    d_out = torch.zeros_like(d_in)
+    torch.cuda.synchronize()
+    with api.Context(640, 100, 1, 1) as ctx:
+        ctx.run_device(d_in.data_ptr(), 640, 640 * 100, d_out.data_ptr(), 640, 640 * 100, 1)
+        ctx.sync()
+        assert ctx.last_run_info() == (False, False, 2)
+        _diff(d_out.cpu().numpy(), oracle.canny_r(img, 10, 40), "in place")
+    img2 = synth.natural(644, 60, 4)   # pitch 644: a multiple of 4 but not of 8
+    d_in2 = torch.from_numpy(img2).cuda()
+    d_out2 = torch.zeros_like(d_in2)
+    torch.cuda.synchronize()
+    with api.Context(644, 60, 1, 1) as ctx:
+        ctx.run_device(d_in2.data_ptr(), 644, 644 * 60, d_out2.data_ptr(), 644, 644 * 60, 1)
+        ctx.sync()
+        assert ctx.last_run_info() == (False, False, 1)
+        _diff(d_out2.cpu().numpy(), oracle.canny_r(img2, 10, 40), "fallback to the 4-px kernels")
+    with api.Context(640, 100, 1, 1, mode=api.MODE_O) as ctx:
+        ctx.run_device(d_in.data_ptr(), 640, 640 * 100, d_out.data_ptr(), 640, 640 * 100, 1)
+        ctx.sync()
+        assert ctx.last_run_info() == (False, False, -1)
