@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     const u32 m1 = pair_shift(A0, Bl), p1 = pair_shift(B0, A0), p3 = pair_shift(A1, B0), p5 = pair_shift(B1, A1), p7 = pair_shift(Ar, B1);
     const u32 Cc[4] = { A0, B0, A1, B1 };
     const u32 Lf[4] = { m1, p1, p3, p5 }, Rt[4] = { p1, p3, p5, p7 };
-    u32 S2[8];
+    u32 T2[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const u32 dk = R(I(Rt[j]) - I(Lf[j]));        // signed halves: packed op
@@ -276,16 +276,18 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
       const u32 X = pk_mad2(dr[rp][j], R(I(dr[rn][j]) + I(dk)));  // sumX = d[i-1] + 2 d[i] + d[i+1] (cannyEdgeD.cu:158-162)
       const u32 Y = R(I(sr[rn][j]) - I(sk));                       // sumY = s[i-1] - s[i+1]        (:163-167)
       // S2 = sumX^2 + sumY^2: the reference's float gradient 4*sqrtf((sumX/8)^2 + (sumY/8)^2) (:195) is a strictly
-      // increasing function of it, so every comparison of gradients is a comparison of S2
-      S2[2 * j] = (u32)mad16<0, 0>(X, X, mul16<0, 0>(Y, Y));
-      S2[2 * j + 1] = (u32)mad16<1, 1>(X, X, mul16<1, 1>(Y, Y));
+      // increasing function of it, so every comparison of gradients is a comparison of S2.  Here only a NECESSARY
+      // condition is needed (the batch decides exactly): the S2 of the pair's two pixels summed -- one v_dot2 each for
+      // sumX and sumY instead of two multiply-adds per pixel -- is at least either of them.  (Summing all four pixels
+      // of the half queues enough half-lanes for nothing to cost more than the two maxima it saves.)
+      T2[j] = (u32)__builtin_amdgcn_sdot2(I(Y), I(Y), sdot2_0(X, X), false);
       dr[rn][j] = dk;
       sr[rn][j] = sk;
     }
     const int c = k - 1;  // the Sobel / output row
     const bool valid = (u32)(c - r0) < (u32)(rend - r0);  // wave-uniform; rows of the neighbouring runs and beyond the image are not ours
-    // half-lanes holding a pixel that passes the low threshold (a necessary condition in every wrap band)
-    const u32 g0 = max(max(S2[0], S2[1]), max(S2[2], S2[3])), g1 = max(max(S2[4], S2[5]), max(S2[6], S2[7]));
+    // half-lanes that may hold a pixel passing the low threshold (itself a necessary condition in every wrap band)
+    const u32 g0 = max(T2[0], T2[1]), g1 = max(T2[2], T2[3]);
     // (pixels right of the image are not masked here: a half-lane queued for nothing costs a batch slot, the batch
     // applies the zero padding exactly; half-lanes entirely outside the image are excluded by the lane masks)
     const u64 mh0 = __ballot(g0 >= a_lo0) & (valid ? lanes0 : 0ull), mh1 = __ballot(g1 >= a_lo0) & (valid ? lanes1 : 0ull);
