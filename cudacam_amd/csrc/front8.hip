@@ -22,9 +22,9 @@
 //             (S % 159 == 0, 0.6 % of them) are queued
 //   fix-up    the queued pixels get the literal 25-fmaf chain of the reference, read from a wave-private LDS ring of
 //             the last 10 masked input rows, and overwrite their byte of the blur ring
-//   phase 2   6 blur rows -> Sobel -> S2 = sumX^2 + sumY^2 -> low-threshold test.  Every byte of the output row is
-//             stored as zero at once; the few half-lanes (4 px) that hold a candidate only queue their identity
-//             (row, lane, half: one dword)
+//   phase 2   6 blur rows -> Sobel -> sumX^2 + sumY^2, summed over pixel pairs -> low-threshold test (a necessary
+//             condition: the batches decide exactly).  Every byte of the output row is stored as zero at once; the
+//             few half-lanes (4 px) that may hold a candidate only queue their identity (row, lane, half: one dword)
 //   NMS       dense batches of 64 queued half-lanes, one per lane: each re-derives the 3 x 6 S2 values around its
 //             4 pixels from the blur ring (5 rows x 12 bytes), applies direction, non-maximum suppression and the two
 //             thresholds, and overwrites its nibble of the planes (and its 4 bytes of the provisional map).  About
