@@ -54,6 +54,14 @@ namespace io
     if (m0 == 'P' && (m1 == '5' || m1 == '6') && pnmToken(f, w) && pnmToken(f, h) && pnmToken(f, maxval) && w > 0 && h > 0 && maxval == 255) {
       const int ch = m1 == '5' ? 1 : 3;
       const std::size_t total = static_cast<std::size_t>(w) * ch * static_cast<std::size_t>(h);
+      // a header may claim any size: nothing is allocated before the file is known to hold that many raster bytes
+      const long at = std::ftell(f);
+      long end = -1;
+      if (at >= 0 && std::fseek(f, 0, SEEK_END) == 0) end = std::ftell(f);
+      if (at < 0 || end < at || static_cast<std::size_t>(end - at) < total || std::fseek(f, at, SEEK_SET) != 0) {
+        std::fclose(f);
+        return false;
+      }
       std::vector<std::uint8_t> img(total);
       ok = std::fread(img.data(), 1, total, f) == total;
       if (ok && ch == 3)
@@ -118,6 +126,9 @@ namespace io
     const int spp = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;// samples per pixel in the file
     if (spp == 0 || (ctype == 3 && plte.size() < 3)) return false;
     const std::size_t stride = static_cast<std::size_t>(w) * spp;
+    // deflate expands by at most 1032 : 1, so a header that claims more pixels than the IDAT bytes can hold is rejected
+    // before anything of that size is allocated (a 60-byte file may claim 65535 x 65535 RGBA)
+    if ((stride + 1) * h > idat.size() * 1032 + 1024) return false;
     std::vector<std::uint8_t> raw((stride + 1) * h);
     uLongf rawLen = static_cast<uLongf>(raw.size());
     if (uncompress(raw.data(), &rawLen, idat.data(), static_cast<uLong>(idat.size())) != Z_OK || rawLen != raw.size()) return false;
