@@ -87,6 +87,7 @@ hipError_t launch_front(const FrontParams &p, hipStream_t s);
 hipError_t launch_front_o(const FrontParams &p, hipStream_t s);
 // front8.hip: the whole front path as one kernel, 8 px per lane (strips of 496 columns, runs of 6 * windows - 4 rows)
 hipError_t launch_front8(const FrontParams &p, hipStream_t s);
+hipError_t launch_front8o(const FrontParams &p, hipStream_t s);  // Mode O on the same skeleton (one-channel sources)
 int front8_run_rows(int windows);
 int front8_strips(int W);
 hipError_t launch_blur(const FrontParams &p, hipStream_t s);

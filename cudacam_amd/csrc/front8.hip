@@ -540,6 +540,311 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   }
 }
 
+// =====================================================================================================================
+// k_front8o -- Mode O (cv::Canny(src, low, high, 3, L2gradient) semantics, OpenCV 4.x modules/imgproc/src/canny.cpp) on
+// the skeleton of k_front8: the same strips, runs, windows, id-only NMS queue and dense batches; no blur, so no phase 1
+// and no fix-up -- the source rows themselves go into the wave's LDS ring.
+//   Sobel 3x3 with BORDER_REPLICATE: rows are replicated by clamping the row of the load; columns outside the image are
+//   stored as zero in the ring, the half-lanes that hold column 0 or W-1 are always queued, and the batch re-derives
+//   their gradients from the replicated bytes (a v_perm per dword, in the border variant of the batch only).
+//   magnitude m = |dx| + |dy| (or dx^2 + dy^2), zero outside the image; m <= low dropped; direction by the integer
+//   tangent test (TG22 = 13573, shift 15); asymmetric non-maximum suppression (m > first neighbour, m >= second on the
+//   axes; strict on both diagonal neighbours); m > high seeds.  (k_front_o in canny_kernels.hip is the 4-px form of the
+//   same arithmetic and still serves 3-channel sources.)
+// Phase 2 queues the half-lanes with a pixel above low: exactly for the L1 magnitude (packed |dx| + |dy|, five
+// instructions per pixel pair; the cheaper pair-summed dx^2 + dy^2 >= ceil((low + 1)^2 / 2) queued three times as many
+// half-lanes as pass, and the batches cost more than the test saves); with L2gradient by the necessary condition
+// dx^2 + dy^2 summed over the pair (two v_dot2) >= low + 1.
+constexpr int F8O_WAVE_BYTES = F8_RING * F8_ROW_BYTES + (F8_NQ + 4) * 4;  // 7,184 B per wave
+
+template <bool L2, bool PROV>
+__global__ __launch_bounds__(256) void k_front8o(const FrontParams p)
+{
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wib = threadIdx.x >> 6;
+  unsigned char *bring = smem + wib * F8O_WAVE_BYTES;  // source rows (columns outside the image zero)
+  lds_u32 *nq = (lds_u32 *)(bring + F8_RING * F8_ROW_BYTES);
+  const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
+  if (item >= p.total_items) return;
+  const int chunk = item % p.nchunks;
+  const int strip = (item / p.nchunks) % p.nstrips;
+  const int frame = item / (p.nchunks * p.nstrips);
+  const int W = p.W, H = p.H;
+  const int r0 = chunk * p.run_rows;  // output rows [r0, rend)
+  const int rend = min(r0 + p.run_rows, H);
+  const int c0 = strip * F8_STRIP_W - F8_HALO + lane * 8;
+  u32 cmask[2] = { 0, 0 };
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const bool in = (c0 + k >= 0) && (c0 + k < W);
+    cmask[k >> 2] |= in ? (0xFFu << (8 * (k & 3))) : 0u;
+  }
+  const bool own_lane = lane >= 1 && lane <= 62;
+  const bool col_any = (cmask[0] | cmask[1]) != 0;
+  const uint8_t *frame_base = p.in + (size_t)frame * p.in_frame_stride;
+  const u32 in_pitch32 = (u32)p.in_pitch;  // launch_front8o checks H * pitch < 2^32 and pitch >= round_up(W, 8)
+  const u32 ld_safe = col_any ? (u32)c0 : 0u;  // lanes without an image column read the row's first bytes (masked)
+  const int rlast = min(H - 1, rend + 1);  // last source row this run needs
+  // unconditional loads; BORDER_REPLICATE down the columns = the row index clamped into the image
+  auto load_raw = [&](int row) -> u32x2 {
+    u32 lo = ld_safe;
+    asm volatile("" : "+v"(lo));
+    const uint8_t *q = frame_base + (u32)min(max(row, 0), rlast) * in_pitch32 + lo;
+    return *reinterpret_cast<const g_u32x2 *>(q);
+  };
+
+  u32 dr[2][4], sr[2][4];  // d = x[+1]-x[-1] and s = x[-1]+2x[0]+x[+1] of the two previous rows, [ring][pair]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) dr[a][b] = sr[a][b] = 0;
+  const size_t plane_off = (size_t)frame * H * p.RD * 4;
+  uint8_t *splane = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
+  uint8_t *cplane = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
+  const u32 plane_pitch = (u32)p.RD * 4u;
+  const bool st_lane = own_lane && col_any;
+  const u32 st_off = st_lane ? (u32)(strip * 62 + lane - 1) : (u32)(strip * 62);
+  const u32 prov_voff = st_lane ? (u32)c0 : (u32)(strip * F8_STRIP_W);
+  const u32 low = p.a_lo[0], high = p.a_hi[0];  // plain thresholds on m (squared by the host for L2gradient)
+  // phase 2's test.  L2gradient: pair-summed dx^2 + dy^2 >= low + 1 (necessary).  L1: the exact magnitudes, packed; `nec`
+  // is the per-half bias that carries "m > low" into bit 15 (thresholds are capped at 32767 by hc_set_thresholds)
+  const u32 nec = L2 ? low + 1u : (0x7FFFu - min(low, 0x7FFFu)) * 0x10001u;
+  const u64 lanes0 = uniform64(__ballot(own_lane && cmask[0] != 0)), lanes1 = uniform64(__ballot(own_lane && cmask[1] != 0));
+  // half-lanes that hold the image's first or last column: their gradients depend on the replicated border, which only
+  // the batch applies -- always queued
+  const u64 bord0 = uniform64(__ballot(own_lane && (c0 == 0 || (c0 <= W - 1 && W - 1 <= c0 + 3))));
+  const u64 bord1 = uniform64(__ballot(own_lane && (c0 + 4 <= W - 1 && W - 1 <= c0 + 7)));
+  uint8_t *prov_frame = PROV ? p.prov_out + (size_t)frame * p.prov_fs : nullptr;
+  const u32 k_tg22 = 13573u, k_m32768 = 0x8000u;  // 16-bit multiplier operands (low halves): TG22 and -2^15
+
+  int qhead = 0, qcount = 0;  // NMS queue (circular, F8_NQ ids): wave-uniform
+  // source row k (its 8 bytes per lane in b0, b1) arrives -> gradient row k-1 -> the row's possible candidates are queued
+  auto step = [&](auto uc, int k, u32 b0, u32 b1) {
+    constexpr int u = decltype(uc)::value;
+    constexpr int rn = u % 2, rp = (u + 1) % 2;
+    const u32 A0 = unpack_lo(b0), B0 = unpack_hi(b0), A1 = unpack_lo(b1), B1 = unpack_hi(b1);
+    const u32 Bl = from_lane_below(B1), Ar = from_lane_above(A0);
+    const u32 m1 = pair_shift(A0, Bl), p1 = pair_shift(B0, A0), p3 = pair_shift(A1, B0), p5 = pair_shift(B1, A1), p7 = pair_shift(Ar, B1);
+    const u32 Cc[4] = { A0, B0, A1, B1 };
+    const u32 Lf[4] = { m1, p1, p3, p5 }, Rt[4] = { p1, p3, p5, p7 };
+    u32 T2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const u32 dk = R(I(Rt[j]) - I(Lf[j]));
+      const u32 sk = pk_mad2(Cc[j], Lf[j] + Rt[j]);
+      const u32 X = pk_mad2(dr[rp][j], R(I(dr[rn][j]) + I(dk)));  // dx = right - left, smoothed 1-2-1 down the rows
+      const u32 Y = R(I(sk) - I(sr[rn][j]));                      // dy = bottom - top
+      if constexpr (L2) T2[j] = (u32)__builtin_amdgcn_sdot2(I(Y), I(Y), sdot2_0(X, X), false);  // pair sum: a necessary condition
+      else T2[j] = R(__builtin_elementwise_max(I(X), -I(X))) + R(__builtin_elementwise_max(I(Y), -I(Y)));  // |dx| + |dy| of both pixels, exact (<= 2040 per half)
+      dr[rn][j] = dk;
+      sr[rn][j] = sk;
+    }
+    const int c = k - 1;  // the gradient / output row
+    const bool valid = (u32)(c - r0) < (u32)(rend - r0);
+    bool q0, q1;  // the half-lane may hold (L2) / holds (L1) a pixel with m > low
+    if constexpr (L2) {
+      q0 = max(T2[0], T2[1]) >= nec; q1 = max(T2[2], T2[3]) >= nec;
+    } else {
+      // any of the four 16-bit magnitudes > low  <=>  bit 15 of (m + 0x7FFF - low) in one of the halves (low <= 32767)
+      const u32 g0 = R(__builtin_elementwise_max(U(T2[0]), U(T2[1]))), g1 = R(__builtin_elementwise_max(U(T2[2]), U(T2[3])));
+      q0 = ((g0 + nec) & 0x80008000u) != 0; q1 = ((g1 + nec) & 0x80008000u) != 0;
+    }
+    const u64 mh0 = (__ballot(q0) | bord0) & (valid ? lanes0 : 0ull), mh1 = (__ballot(q1) | bord1) & (valid ? lanes1 : 0ull);
+    {
+      typedef __attribute__((address_space(1))) uint8_t gmem_u8;
+      typedef __attribute__((address_space(1))) g_u32x2 gmem_u32x2;
+      gmem_u8 *sp = (gmem_u8 *)uniform_sel(valid, splane + (u32)c * plane_pitch, p.dump), *cp = (gmem_u8 *)uniform_sel(valid, cplane + (u32)c * plane_pitch, p.dump + 2048);
+      u32 so = st_off;
+      asm volatile("" : "+v"(so));
+      sp[so] = 0;
+      cp[so] = 0;
+      if constexpr (PROV) {
+        gmem_u8 *pp = (gmem_u8 *)uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump + 4096);
+        u32 o = prov_voff;
+        asm volatile("" : "+v"(o));
+        *reinterpret_cast<gmem_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
+      }
+    }
+    const u32 below = mbcnt64(mh0) + mbcnt64(mh1);
+    const u32 idbase = ((u32)c << 8) | (u32)lane;
+    const u32 pos0 = ((u32)(qhead + qcount) + below) & (u32)(F8_NQ - 1);
+    const u32 pos1 = (pos0 + lane_sel(mh0, 1u, 0u)) & (u32)(F8_NQ - 1);
+    nq[lane_sel(mh0, pos0, (u32)F8_NQ)] = idbase | lane_sel(mh1, 0x80u, 0u);
+    nq[lane_sel(mh1, pos1, (u32)F8_NQ)] = idbase | 0x40u;
+    u32 n0, n1;
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n0) : "s"(mh0) : "scc");
+    asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n1) : "s"(mh1) : "scc");
+    qcount += (int)(n0 + n1);
+  };
+
+  // One dense NMS pass: up to 64 queued half-lanes, an entry per lane.  sbase: ring slot of source row bw0 - 4.
+  auto nms_batch = [&](int nwant, int bw0, u32 sbase) {
+    wave_lds_sync();
+    int nent = nwant;
+    {  // never split a lane's pair of entries over two batches
+      const u32 idl = nq[(u32)(qhead + nent - 1) & (u32)(F8_NQ - 1)];
+      if (__builtin_amdgcn_readfirstlane((int)idl) & 0x80) nent -= 1;
+    }
+    const bool live = lane < nent;
+    const u32 id = nq[(u32)(qhead + lane) & (u32)(F8_NQ - 1)];
+    const u32 sl = live ? (id & 63u) : 1u, half = (id >> 6) & 1u;
+    const int row = live ? (int)(id >> 8) : bw0;
+    const int col0 = strip * F8_STRIP_W - F8_HALO + 8 * (int)sl + 4 * (int)half;  // column of the half's pixel 0
+    const u32 rel = (u32)(row - (bw0 - 2));
+    const u32 lo = sl * 8u + half * 4u - 4u;
+    // pixels -2 .. 5 of the entry lie outside the image's columns somewhere, or its rows -1 / +1 outside the image
+    const bool at_border = live && (col0 == 0 || col0 + 5 >= W || row == 0 || row + 1 >= H);
+    u32 XU[3], YU[3], XC[3], YC[3], XN[3], YN[3];
+    auto sobel = [&](auto masked) {
+      constexpr bool MASKED = decltype(masked)::value;
+      u32 selA = 0, selB = 0, pm[3] = { ~0u, ~0u, ~0u }, mU = ~0u, mN = ~0u;
+      if constexpr (MASKED) {
+        // BORDER_REPLICATE along the row: byte t of the 8-byte window (columns col0-2 .. col0+5) comes from the column
+        // clamped into the image, which lies in the same window
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          const u32 idx = (u32)(min(max(col0 - 2 + t, 0), W - 1) - (col0 - 2)) & 7u;
+          if (t < 4) selA |= idx << (8 * t);
+          else selB |= idx << (8 * (t - 4));
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {  // magnitudes outside the image are zero
+          const u32 vlo = (u32)(col0 + 2 * j - 1) < (u32)W ? 0x0000FFFFu : 0u, vhi = (u32)(col0 + 2 * j) < (u32)W ? 0xFFFF0000u : 0u;
+          pm[j] = vlo | vhi;
+        }
+        mU = row > 0 ? 0xFFFFFFFFu : 0u;
+        mN = row + 1 < H ? 0xFFFFFFFFu : 0u;
+      }
+      u32 d[5][3], s[5][3];
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        u32 slot = sbase + rel + (u32)r;
+        slot = min(slot, slot - (u32)F8_RING);
+        const u32 *q = reinterpret_cast<const u32 *>(bring + slot * (u32)F8_ROW_BYTES + lo);
+        const u32 D0 = q[0], D1 = q[1], D2 = q[2];
+        u32 Pm, A, B, Cq;  // (b-2,b-1) (b0,b1) (b2,b3) (b4,b5)
+        if constexpr (MASKED) {
+          const u32 E0 = __builtin_amdgcn_alignbyte(D1, D0, 2), E1 = __builtin_amdgcn_alignbyte(D2, D1, 2);  // bytes -2..1, 2..5
+          const u32 F0 = __builtin_amdgcn_perm(E1, E0, selA), F1 = __builtin_amdgcn_perm(E1, E0, selB);
+          Pm = unpack_lo(F0); A = unpack_hi(F0); B = unpack_lo(F1); Cq = unpack_hi(F1);
+        } else {
+          Pm = unpack_hi(D0); A = unpack_lo(D1); B = unpack_hi(D1); Cq = unpack_lo(D2);
+        }
+        const u32 c0p = pair_shift(A, Pm), c1p = pair_shift(B, A), c2p = pair_shift(Cq, B);  // (b-1,b0) (b1,b2) (b3,b4)
+        d[r][0] = R(I(A) - I(Pm)); d[r][1] = R(I(B) - I(A)); d[r][2] = R(I(Cq) - I(B));
+        s[r][0] = pk_mad2(c0p, Pm + A); s[r][1] = pk_mad2(c1p, A + B); s[r][2] = pk_mad2(c2p, B + Cq);
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        XU[j] = pk_mad2(d[1][j], R(I(d[0][j]) + I(d[2][j]))); YU[j] = R(I(s[2][j]) - I(s[0][j]));
+        XC[j] = pk_mad2(d[2][j], R(I(d[1][j]) + I(d[3][j]))); YC[j] = R(I(s[3][j]) - I(s[1][j]));
+        XN[j] = pk_mad2(d[3][j], R(I(d[2][j]) + I(d[4][j]))); YN[j] = R(I(s[4][j]) - I(s[2][j]));
+        if constexpr (MASKED) {
+          XU[j] &= pm[j] & mU; YU[j] &= pm[j] & mU;
+          XC[j] &= pm[j]; YC[j] &= pm[j];
+          XN[j] &= pm[j] & mN; YN[j] &= pm[j] & mN;
+        }
+      }
+    };
+    if (__ballot(at_border) != 0) sobel(std::true_type{});
+    else sobel(std::false_type{});
+    // magnitudes of pixels -1 .. 4 in the rows above / of / below the entry: index t + 1
+    u32 MU[6], MC[6], MN[6], aXc[3], aYc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      aXc[j] = R(__builtin_elementwise_max(I(XC[j]), -I(XC[j])));
+      aYc[j] = R(__builtin_elementwise_max(I(YC[j]), -I(YC[j])));
+      if constexpr (L2) {
+        MU[2 * j] = (u32)mad16<0, 0>(XU[j], XU[j], mul16<0, 0>(YU[j], YU[j])); MU[2 * j + 1] = (u32)mad16<1, 1>(XU[j], XU[j], mul16<1, 1>(YU[j], YU[j]));
+        MC[2 * j] = (u32)mad16<0, 0>(XC[j], XC[j], mul16<0, 0>(YC[j], YC[j])); MC[2 * j + 1] = (u32)mad16<1, 1>(XC[j], XC[j], mul16<1, 1>(YC[j], YC[j]));
+        MN[2 * j] = (u32)mad16<0, 0>(XN[j], XN[j], mul16<0, 0>(YN[j], YN[j])); MN[2 * j + 1] = (u32)mad16<1, 1>(XN[j], XN[j], mul16<1, 1>(YN[j], YN[j]));
+      } else {  // |dx| + |dy| <= 2040 per half: one add on both halves
+        const u32 mu = R(__builtin_elementwise_max(I(XU[j]), -I(XU[j]))) + R(__builtin_elementwise_max(I(YU[j]), -I(YU[j])));
+        const u32 mc = aXc[j] + aYc[j];
+        const u32 mn = R(__builtin_elementwise_max(I(XN[j]), -I(XN[j]))) + R(__builtin_elementwise_max(I(YN[j]), -I(YN[j])));
+        MU[2 * j] = mu & 0xFFFFu; MU[2 * j + 1] = mu >> 16;
+        MC[2 * j] = mc & 0xFFFFu; MC[2 * j + 1] = mc >> 16;
+        MN[2 * j] = mn & 0xFFFFu; MN[2 * j + 1] = mn >> 16;
+      }
+    }
+    u32 nibS = 0, nibC = 0;
+    // pixel q lives in pair (q + 1) / 2, half (q + 1) % 2 of the pairs (-1,0), (1,2), (3,4)
+    auto px = [&](auto qc) {
+      constexpr int q = decltype(qc)::value, j = (q + 1) / 2, e = (q + 1) % 2;
+      const u32 m = MC[1 + q];
+      // tangent test on x = |dx|, y = |dy| (canny.cpp): horizontal if y*2^15 < x*TG22, vertical if y*2^15 > x*(TG22 + 2^16)
+      const int E = mad16<e, 0>(aYc[j], k_m32768, mul16<e, 0>(aXc[j], k_tg22));  // x*TG22 - y*2^15
+      const int x16 = (int)(e ? (aXc[j] & 0xFFFF0000u) : (aXc[j] << 16));       // x * 2^16
+      const bool hz = E > 0, vt = E + x16 < 0;
+      const bool dneg = mul16<e, e>(XC[j], YC[j]) < 0;  // sign(dx) != sign(dy): the diagonal that runs up-right / down-left
+      // first neighbour (strict), second neighbour (>= on the axes, strict on the diagonals)
+      const u32 n1 = hz ? MC[q] : vt ? MU[1 + q] : dneg ? MU[2 + q] : MU[q];
+      const u32 n2 = hz ? MC[2 + q] : vt ? MN[1 + q] : dneg ? MN[q] : MN[2 + q];
+      const bool keep = m > n1 && m + ((hz || vt) ? 1u : 0u) > n2;
+      nibS |= (m > high && keep) ? (1u << q) : 0u;
+      nibC |= (m > low && keep) ? (1u << q) : 0u;
+    };
+    px(std::integral_constant<int, 0>{});
+    px(std::integral_constant<int, 1>{});
+    px(std::integral_constant<int, 2>{});
+    px(std::integral_constant<int, 3>{});
+    const u32 nib = nibS | (nibC << 8);  // pixels outside the image have m = 0: never above low
+    const u32 nxt = from_lane_above(nib);
+    const bool first = (id & 0x80u) != 0;
+    const u32 prev_id = from_lane_below(id);
+    const bool second = lane > 0 && (prev_id & 0x80u) != 0;
+    const u32 w = first ? (nib | (nxt << 4)) : (nib << (4 * half));
+    if (live && !second) {
+      const u32 o = (u32)row * plane_pitch + (u32)(strip * 62) + sl - 1u;
+      splane[o] = (uint8_t)w;
+      cplane[o] = (uint8_t)(w >> 8);
+    }
+    if (PROV && live)
+      *reinterpret_cast<u32 *>(prov_frame + (u32)row * p.prov_pitch + (u32)col0) = nibble_to_bytes(nib & 0xFu);
+    qhead = (qhead + nent) & (F8_NQ - 1);
+    qcount -= nent;
+  };
+
+  // ---- the run: source rows r0-2 .. rend+1 -> gradient / output rows r0 .. rend-1 ---------------------------------------
+  u32x2 xn[F8_SUB];
+#pragma unroll
+  for (int j = 0; j < F8_SUB; ++j) xn[j] = load_raw(r0 - 2 + j);
+  const int nwin = (rend + 2 - (r0 - 2) + F8_SUB - 1) / F8_SUB;
+  int bslot0 = 0;  // ring slot of the window's first source row (row r0 - 2 sits in slot 0)
+#pragma nounroll
+  for (int w = 0; w < nwin; ++w) {
+    const int bw0 = r0 - 2 + w * F8_SUB;  // the window brings source rows bw0 .. bw0+5 and produces output rows bw0-2 .. bw0+3
+#pragma unroll
+    for (int j = 0; j < F8_SUB; ++j) {
+      const u32x2 x = u32x2{ xn[j].x & cmask[0], xn[j].y & cmask[1] };
+      xn[j] = load_raw(bw0 + j + F8_SUB);
+      const int bs = bslot0 + j;
+      *reinterpret_cast<u32x2 *>(bring + (bs >= F8_RING ? bs - F8_RING : bs) * F8_ROW_BYTES + lane * 8) = x;
+    }
+    wave_lds_sync();
+    int sb = bslot0 - 4;  // ring slot of source row bw0 - 4
+    if (sb < 0) sb += F8_RING;
+    u32x2 bq[F8_SUB];  // rows bw0-1 .. bw0+4 (the first one is the previous window's last)
+#pragma unroll
+    for (int j = 0; j < F8_SUB; ++j) {
+      int bs = bslot0 + j - 1;
+      bs = bs < 0 ? bs + F8_RING : bs >= F8_RING ? bs - F8_RING : bs;
+      bq[j] = *reinterpret_cast<const u32x2 *>(bring + bs * F8_ROW_BYTES + lane * 8);
+    }
+    step(std::integral_constant<int, 0>{}, bw0 - 1, bq[0].x, bq[0].y);
+    step(std::integral_constant<int, 1>{}, bw0 + 0, bq[1].x, bq[1].y);
+    step(std::integral_constant<int, 2>{}, bw0 + 1, bq[2].x, bq[2].y);
+    while (qcount >= 64) nms_batch(64, bw0, (u32)sb);
+    step(std::integral_constant<int, 3>{}, bw0 + 2, bq[3].x, bq[3].y);
+    step(std::integral_constant<int, 4>{}, bw0 + 3, bq[4].x, bq[4].y);
+    step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
+    while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
+    wave_lds_sync();  // the next window overwrites the oldest ring rows
+    bslot0 = bslot0 + F8_SUB >= F8_RING ? bslot0 + F8_SUB - F8_RING : bslot0 + F8_SUB;
+  }
+}
+
 template <int IN>
 static hipError_t launch_front8_t(const FrontParams &p, hipStream_t s)
 {
@@ -562,6 +867,27 @@ hipError_t launch_front8(const FrontParams &p, hipStream_t s)
   if (p.dbg_blur && p.dbg_pitch < w8) return hipErrorInvalidValue;
   if (!p.dump || !p.zeros) return hipErrorInvalidValue;
   return p.bgr == 2 ? launch_front8_t<2>(p, s) : p.bgr == 1 ? launch_front8_t<1>(p, s) : launch_front8_t<0>(p, s);
+}
+
+// Mode O, one-channel source: same strips and run lengths as launch_front8 (p.bgr must be 0; p.l2gradient selects the magnitude)
+hipError_t launch_front8o(const FrontParams &p, hipStream_t s)
+{
+  const int windows = (p.run_rows + 4) / F8_SUB;
+  if (windows < 1 || p.run_rows != front8_run_rows(windows) || p.nchunks * p.run_rows < p.H || p.nstrips != front8_strips(p.W) || p.bgr) return hipErrorInvalidValue;
+  const size_t w8 = ((size_t)p.W + 7) / 8 * 8;
+  if ((unsigned long long)p.H * p.in_pitch >= (1ull << 32) || p.in_pitch < w8) return hipErrorInvalidValue;
+  if (p.prov_out && (p.W % 8 != 0)) return hipErrorInvalidValue;
+  if (!p.dump) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((p.total_items + 3) / 4)), block(256);
+  const size_t lds = (size_t)4 * F8O_WAVE_BYTES;
+  if (p.l2gradient) {
+    if (p.prov_out) hipLaunchKernelGGL((k_front8o<true, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_front8o<true, false>), grid, block, lds, s, p);
+  } else {
+    if (p.prov_out) hipLaunchKernelGGL((k_front8o<false, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_front8o<false, false>), grid, block, lds, s, p);
+  }
+  return hipGetLastError();
 }
 
 }  // namespace hc

@@ -408,8 +408,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     fp.total_items = n_out * fp.nstrips * fp.nchunks;
     // Mode R front path: k_front8 reads whole 8-pixel groups (8 or 24 bytes per lane and row), the 4-px kernels 4-pixel groups
     const bool can8 = sp >= round_up((size_t)W, 8) * (size_t)(fuse_bgr || c->per_channel ? 3 : 1);
-    const int form = c->mode != HC_MODE_R ? -1 : (c->split == 2 && !can8) ? 1 : c->split;
-    const bool split = form == 1, f8 = form == 2;
+    // Mode O: k_front8o (form 3) for one-channel sources, the 4-px k_front_o (form -1) for 3-channel ones, for rows that
+    // do not hold whole 8-pixel groups, or when HC_OPT_FRONT_SPLIT asks for a 4-px form
+    const int form = c->mode != HC_MODE_R ? ((c->C == 1 && c->split == 2 && can8) ? 3 : -1) : (c->split == 2 && !can8) ? 1 : c->split;
+    const bool split = form == 1, f8 = form == 2 || form == 3;
     c->last_front_form = form;
     // Pipelined mode: k_nms / k_front_o also write the strong pixels as 255 into the output (4 px per lane: whole
     // dwords need W % 4 == 0), so that the hysteresis, which runs beside the next run's bandwidth-hungry k_blur, only
@@ -423,7 +425,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     // continuation rewrites whole maps (finish_slot) and would otherwise land on top of this run's result
     if (out_overlap)
       if (int rc = finish_slot(c, c->slot[c->cur ^ 1])) return rc;
-    s.prov = piped && !out_overlap && ((W % 4 == 0 && (split || c->mode == HC_MODE_O)) || (W % 8 == 0 && f8));
+    s.prov = piped && !out_overlap && (f8 ? W % 8 == 0 : (W % 4 == 0 && (split || c->mode == HC_MODE_O)));
     if (piped) { c->prev_out0 = o0; c->prev_out1 = o1; }
     if (s.prov) { fp.prov_out = dst; fp.prov_pitch = (u32)dp; fp.prov_fs = dfs; }
     if (c->debug_taps) {
@@ -473,13 +475,17 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
         fp.a_lo[0] = (u32)c->low * (u32)c->low;
         fp.a_hi[0] = (u32)c->high * (u32)c->high;
       }
-      const long units = (long)n_out * c->nstrips;
-      const int per_strip = (int)std::max<long>(1, std::min<long>((12288 + units - 1) / units, (H + 15) / 16));
-      fp.chunk_rows = (H + per_strip - 1) / per_strip;
-      fp.nchunks = (H + fp.chunk_rows - 1) / fp.chunk_rows;
-      fp.total_items = n_out * fp.nstrips * fp.nchunks;
-      if (sp < round_up((size_t)W, 4) * (size_t)c->C) return fail(HC_E_ARG, "mode O needs an input pitch of at least round_up(width, 4) * channels");
-      HIPCK(launch_front_o(fp, sf));
+      if (f8) {
+        HIPCK(launch_front8o(fp, sf));  // strips and runs as set for k_front8 above
+      } else {
+        const long units = (long)n_out * c->nstrips;
+        const int per_strip = (int)std::max<long>(1, std::min<long>((12288 + units - 1) / units, (H + 15) / 16));
+        fp.chunk_rows = (H + per_strip - 1) / per_strip;
+        fp.nchunks = (H + fp.chunk_rows - 1) / fp.chunk_rows;
+        fp.total_items = n_out * fp.nstrips * fp.nchunks;
+        if (sp < round_up((size_t)W, 4) * (size_t)c->C) return fail(HC_E_ARG, "mode O needs an input pitch of at least round_up(width, 4) * channels");
+        HIPCK(launch_front_o(fp, sf));
+      }
       HIPCK(mark(sf, B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));  // cv::Canny has no blur stage
     } else {
       band_thresholds(c->low, c->nms_saturate != 0, fp.a_lo);

@@ -127,8 +127,9 @@ int hc_last_hysteresis_info(hc_ctx *ctx, int *launches_with_work, int *continued
 /* What the last hc_run / hc_run_device did with the caller's buffers -- no silent cliffs: *input_staged / *output_staged are
  * 1 when the frames went through the context's internal pitched buffers (an extra device-to-device copy each: pointer,
  * pitch or frame stride not a multiple of 4, or 3-channel mode O rows without whole 12-byte groups), and *front_form is
- * the front path that ran (HC_OPT_FRONT_SPLIT value 2 / 1 / 0; -1 for mode O and for final stages below HYSTER): a
- * context set to k_front8 falls back to k_blur + k_nms when a row does not hold whole 8-pixel groups. */
+ * the front path that ran (Mode R: the HC_OPT_FRONT_SPLIT value 2 / 1 / 0; Mode O: 3 = k_front8o, -1 = k_front_o; -1
+ * also for final stages below HYSTER): a context set to k_front8 falls back to k_blur + k_nms (Mode O: to k_front_o)
+ * when a row does not hold whole 8-pixel groups. */
 int hc_last_run_info(hc_ctx *ctx, int *input_staged, int *output_staged, int *front_form);
 
 /* Diagnostics of the last run's queued hysteresis launches: 3 words per launch
@@ -163,7 +164,8 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * 2 = k_front8: ONE kernel, 8 pixels per lane, no intermediate in HBM (falls back to 1 when an input row does not hold
  * whole 8-pixel groups, i.e. pitch < round_up(width, 8) * channels); 1 = k_blur + k_nms with a u8 blur plane between
  * them; 0 = k_front, the earlier 4-pixel fused kernel.  Results are identical; 0 and 1 are kept as independent
- * implementations for the parity tests.
+ * implementations for the parity tests.  Mode O contexts: 2 = k_front8o, the 8-pixel kernel (one-channel sources;
+ * 3-channel sources and rows without whole 8-pixel groups use k_front_o), 0 or 1 = k_front_o, the 4-pixel kernel.
  *
  * HC_OPT_L2_GRADIENT (default 0, Mode O contexts): cv::Canny's `L2gradient` argument: magnitude dx^2 + dy^2
  * compared with the squared thresholds instead of |dx| + |dy|. */

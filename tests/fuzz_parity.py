@@ -36,7 +36,7 @@ for i in range(cases):
         opts["sat"] = int(rng.integers(0, 2)); opts["split"] = int(rng.choice([2, 2, 2, 1, 0])); opts["chunk"] = int(rng.choice([0, 2, 8, 9, 24, 50, 122, 400]))   # split: 2 k_front8, 1 k_blur + k_nms, 0 k_front
         want = np.stack([O.canny_r(f, low, high, saturate=bool(opts["sat"])) for f in frames])
     else:
-        opts["l2"] = int(rng.integers(0, 2))
+        opts["l2"] = int(rng.integers(0, 2)); opts["split"] = int(rng.choice([2, 2, 0])); opts["chunk"] = int(rng.choice([0, 2, 8, 9, 24, 50, 122, 400]))   # split: 2 k_front8o, 0 k_front_o
         want = np.stack([O.canny_o(f, low, high, l2gradient=bool(opts["l2"])) for f in frames])
     ch = 1
     if mode == "O" and rng.random() < 0.3:   # cv::Canny on 3-channel input: per pixel the channel with the largest magnitude
@@ -59,7 +59,7 @@ for i in range(cases):
         if mode == "R":
             ctx.set_option(api.OPT_NMS_SATURATE, opts["sat"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)
         else:
-            ctx.set_option(api.OPT_L2_GRADIENT, opts["l2"])
+            ctx.set_option(api.OPT_L2_GRADIENT, opts["l2"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)
         taps = mode == "R" and rng.random() < 0.3
         if taps:
             ctx.set_option(api.OPT_DEBUG_TAPS, 1)

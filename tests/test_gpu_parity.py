@@ -545,7 +545,7 @@ def test_pipelined_one_buffer_with_host_continuation(oracle):
 
 def test_last_run_info_reports_form_and_staging(oracle):
     """Aligned caller buffers are used in place by k_front8; a row that does not hold whole 8-pixel groups falls back to
-    k_blur + k_nms (and says so); mode O reports no Mode R front form."""
+    k_blur + k_nms (and says so); mode O reports k_front8o (3), or the 4-px k_front_o (-1) when asked for a 4-px form."""
     import torch
     img = synth.natural(640, 100, 3)
     d_in = torch.from_numpy(img).cuda()
@@ -568,4 +568,10 @@ def test_last_run_info_reports_form_and_staging(oracle):
     with api.Context(640, 100, 1, 1, mode=api.MODE_O) as ctx:
         ctx.run_device(d_in.data_ptr(), 640, 640 * 100, d_out.data_ptr(), 640, 640 * 100, 1)
         ctx.sync()
+        assert ctx.last_run_info() == (False, False, 3)
+        _diff(d_out.cpu().numpy(), oracle.canny_o(img, 50, 150), "mode O in place")
+        ctx.set_option(api.OPT_FRONT_SPLIT, 1)
+        ctx.run_device(d_in.data_ptr(), 640, 640 * 100, d_out.data_ptr(), 640, 640 * 100, 1)
+        ctx.sync()
         assert ctx.last_run_info() == (False, False, -1)
+        _diff(d_out.cpu().numpy(), oracle.canny_o(img, 50, 150), "mode O, 4-px kernel")

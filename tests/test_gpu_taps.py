@@ -96,18 +96,23 @@ def test_front_taps_bgr_and_per_channel(oracle, form, split):
             _diff(got[ch], edges, f"channel {ch} {form}: edges")
 
 
+@pytest.mark.parametrize("form", ["front8o", "front_o"])
 @pytest.mark.parametrize("l2", [0, 1])
 @pytest.mark.parametrize("name,img", list(_images()), ids=[n for n, _ in _images()])
-def test_front_taps_mode_o(oracle, name, img, l2):
+def test_front_taps_mode_o(oracle, name, img, l2, form):
+    """Mode O: the bit planes the front kernel hands to the hysteresis equal cv::Canny's map before its flood (the CPU
+    restatement's), for the 8-px k_front8o (default) and the 4-px k_front_o."""
     h, w = img.shape
     low, high = (50, 150) if not l2 else (40, 120)
     edges, pre = oracle.canny_o_stages(img, low, high, bool(l2))
     with api.Context(w, h, 1, 1, mode=api.MODE_O) as ctx:
         ctx.set_thresholds(low, high)
         ctx.set_option(api.OPT_L2_GRADIENT, l2)
+        ctx.set_option(api.OPT_FRONT_SPLIT, 2 if form == "front8o" else 0)
         ctx.set_option(api.OPT_DEBUG_TAPS, 1)
         got = ctx.process(img)[0]
-        _diff(ctx.debug_tap(api.TAP_THRESH)[0], pre, f"{name} mode O l2={l2}: bit planes of k_front_o")
+        assert ctx.last_run_info()[2] == (3 if form == "front8o" else -1)
+        _diff(ctx.debug_tap(api.TAP_THRESH)[0], pre, f"{name} mode O l2={l2}: bit planes of {form}")
         _diff(got, edges, f"{name} mode O l2={l2}: edges")
         with pytest.raises(api.HipCannyError):
             ctx.debug_tap(api.TAP_BLUR)
