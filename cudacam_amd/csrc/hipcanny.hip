@@ -31,8 +31,10 @@ size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr int MAX_HYST_LAUNCHES = 48;
 constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0 .. MAX) launch flags, then 3 diagnostic words per launch
 
-// Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's
-// hysteresis (pipelined mode); the plain mode only uses slot 0.
+// Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's hysteresis (pipelined
+// mode); the plain mode only uses slot 0.  (Three were measured: run i+1 then no longer waits for the hysteresis of run
+// i-1 -- no difference at 1080p in either mode, the two kernels share the device anyway.)
+constexpr int NSLOT = 2;
 struct Slot {
   u32 *d_sbits = nullptr, *d_cbits = nullptr;  // bit planes [max_batch][H][RD]
   uint8_t *d_tflags = nullptr;
@@ -46,6 +48,7 @@ struct Slot {
   int k_launches = 0;            // hysteresis launches queued for this run
   bool prov = false;             // this run's k_nms wrote the provisional output
   hipStream_t stream = nullptr;  // stream the hysteresis of this run was queued on
+  uintptr_t out0 = 0, out1 = 0;  // output range of this (pipelined, still pending) run: a later run into the same memory waits for it
 };
 }  // namespace
 
@@ -62,12 +65,14 @@ struct hc_ctx {
   uint8_t *d_blur = nullptr, *d_nms = nullptr;
   int16_t *d_sx = nullptr, *d_sy = nullptr;
   // fused path
-  Slot slot[2];
+  Slot slot[NSLOT];
   int cur = 0;
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
+  int hyst_rows_last = 0;              // rows per wave of the last run's hysteresis tiles
+  int hyst_waves_last = 0;             // waves per hysteresis workgroup of the last run (adaptive tile height, queue_hyst_expand)
+  bool hyst_waves_last_small = false;  // ... and whether that run was a pipelined one (different base shape)
   int split = 2;        // Mode R front path: 2 = k_front8 (one kernel, 8 px per lane; default), 1 = k_blur + k_nms, 0 = the 4-px fused k_front
-  uintptr_t prev_out0 = 0, prev_out1 = 0;  // output range of the previous pipelined run (provisional-map hazard check)
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
   uint8_t *d_dump = nullptr;    // k_front8's dump area (FrontParams::dump), followed by its page of zeros (FrontParams::zeros)
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
@@ -231,6 +236,7 @@ int finish_slot(hc_ctx *c, Slot &s)
 {
   if (!s.pending) return HC_OK;
   s.pending = false;
+  s.out0 = s.out1 = 0;  // (this function only returns when the run is complete)
   hipStream_t st = s.stream;
   HIPCK(hipEventSynchronize(s.ev_done));
   const int K = s.k_launches;
@@ -266,10 +272,9 @@ int finish_slot(hc_ctx *c, Slot &s)
 
 int finish_all(hc_ctx *c)
 {
-  // oldest first
-  if (int rc = finish_slot(c, c->slot[c->cur])) return rc;
-  if (int rc = finish_slot(c, c->slot[c->cur ^ 1])) return rc;
-  c->prev_out0 = c->prev_out1 = 0;  // nothing is in flight any more
+  // oldest first: slot `cur` is the next to be reused
+  for (int k = 0; k < NSLOT; ++k)
+    if (int rc = finish_slot(c, c->slot[(c->cur + k) % NSLOT])) return rc;
   return HC_OK;
 }
 
@@ -285,6 +290,14 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // tall enough for about 20 launches, and queue as many launches as the last ones needed, + 2 -- a stream of similar
   // frames stops needing the host-side continuation (which stalls the pipeline) after its first step.
   while (hp.waves < 8 && c->hyst_need_rows > 20 * hp.tile_rows * hp.waves) hp.waves *= 2;
+  // ... and stay with them while the runs still need more than 4 launches there: the launch count at tall tiles says
+  // little about the count at shorter ones (Mode O frames: 6 launches at 128 rows, 22 at 64 -- coming back down by the
+  // row estimate alone made the shape flip every few runs, each flip a host-side continuation that stalls the pipeline
+  // for a millisecond)
+  if (c->hyst_waves_last > hp.waves && small_tiles == c->hyst_waves_last_small && hp.tile_rows == c->hyst_rows_last && c->hyst_need_rows > 4 * hp.tile_rows * c->hyst_waves_last) hp.waves = c->hyst_waves_last;
+  c->hyst_waves_last = hp.waves;
+  c->hyst_waves_last_small = small_tiles;
+  c->hyst_rows_last = hp.tile_rows;
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
   hp.npanels = (c->RD + 63) / 64;
   // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
@@ -329,7 +342,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   Slot &s = c->slot[piped ? c->cur : 0];
   if (piped) {
     if (int rc = alloc_slot(c, s)) return rc;
-    if (int rc = finish_slot(c, s)) return rc;  // the run that used this slot two steps ago
+    if (int rc = finish_slot(c, s)) return rc;  // the run that used this slot NSLOT steps ago
   } else if (int rc = finish_all(c)) return rc;
   // streams: the front kernels always run on the context stream, in order with the caller's own work on it (whatever
   // it did to the input before this call, whatever it does to it afterwards); pipelined mode puts the rest on s_hyst.
@@ -420,13 +433,21 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     // Not when this run's output overlaps the previous run's (a caller that keeps one output buffer): that run's
     // hysteresis may still be patching it, and a late patch would survive into this run's map.
     const uintptr_t o0 = (uintptr_t)dst, o1 = o0 + (size_t)n_out * dfs;
-    const bool out_overlap = piped && c->prev_out0 < o1 && o0 < c->prev_out1;
-    // ... and that run is completed first: should its queued launches not have reached the fixpoint, its host-side
-    // continuation rewrites whole maps (finish_slot) and would otherwise land on top of this run's result
-    if (out_overlap)
-      if (int rc = finish_slot(c, c->slot[c->cur ^ 1])) return rc;
+    bool out_overlap = false;
+    if (piped) {
+      // ... and that run is completed first: should its queued launches not have reached the fixpoint, its host-side
+      // continuation rewrites whole maps (finish_slot) and would otherwise land on top of this run's result.  The same
+      // for an older run still in flight (a caller that alternates two output buffers): it is waited for, oldest first
+      // (once complete it patches nothing any more, so the shortcut stays).
+      for (int k = 1; k < NSLOT; ++k) {
+        Slot &o = c->slot[(c->cur + k) % NSLOT];  // k = NSLOT - 1: the previous run
+        if (!(o.out0 < o1 && o0 < o.out1)) continue;
+        if (k == NSLOT - 1) out_overlap = true;
+        if (int rc = finish_slot(c, o)) return rc;
+      }
+    }
     s.prov = piped && !out_overlap && (f8 ? W % 8 == 0 : (W % 4 == 0 && (split || c->mode == HC_MODE_O)));
-    if (piped) { c->prev_out0 = o0; c->prev_out1 = o1; }
+    if (piped) { s.out0 = o0; s.out1 = o1; }
     if (s.prov) { fp.prov_out = dst; fp.prov_pitch = (u32)dp; fp.prov_fs = dfs; }
     if (c->debug_taps) {
       if (int rc = ensure_debug_buffers(c)) return rc;
@@ -554,7 +575,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     c->ev_count++;
   }
   if (stage == HC_STAGE_HYSTER) HIPCK(hipEventRecord(s.ev_done, sh));
-  if (piped) c->cur ^= 1;
+  if (piped) c->cur = (c->cur + 1) % NSLOT;
   c->last_run_n = n_out;
   return HC_OK;
 }
@@ -649,8 +670,7 @@ void hc_destroy(hc_ctx *c)
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (void *q : { (void *)c->d_in, (void *)c->d_mono, (void *)c->d_out, (void *)c->d_blur, (void *)c->d_nms, (void *)c->d_sx, (void *)c->d_sy, (void *)c->d_bplane, (void *)c->d_dump }) (void)hipFree(q);
-  free_slot(c->slot[0]);
-  free_slot(c->slot[1]);
+  for (Slot &q : c->slot) free_slot(q);
   free_debug_buffers(c);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
   for (hipStream_t st : { c->own_stream, c->s_hyst }) if (st) (void)hipStreamDestroy(st);
@@ -714,9 +734,7 @@ int hc_set_option(hc_ctx *c, int option, int value)
     if ((value != 0) != (c->per_channel != 0)) {  // output-side buffers change size: 3 edge maps per input frame
       HIPCK(hipSetDevice(c->device));
       HIPCK(hipDeviceSynchronize());
-      const bool had1 = c->slot[1].d_sbits != nullptr;
-      free_slot(c->slot[0]);
-      free_slot(c->slot[1]);
+      for (Slot &q : c->slot) free_slot(q);  // (the slots beyond the first are allocated again by the pipelined runs that need them)
       (void)hipFree(c->d_out);
       c->d_out = nullptr;
       c->per_channel = value != 0;
@@ -724,7 +742,6 @@ int hc_set_option(hc_ctx *c, int option, int value)
       if (c->d_bplane) { (void)hipFree(c->d_bplane); c->d_bplane = nullptr; c->bplane_frames = 0; }
       if (alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)c->W, c->H, c->max_batch * (c->per_channel ? 3 : 1)) != HC_OK) return HC_E_HIP;
       if (alloc_slot(c, c->slot[0]) != HC_OK) return HC_E_HIP;
-      if (had1 && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;
     }
   } else if (option == HC_OPT_FRONT_SPLIT) {
     if (value < 0 || value > 2) return fail(HC_E_ARG, "HC_OPT_FRONT_SPLIT: 0 (k_front), 1 (k_blur + k_nms) or 2 (k_front8)");
@@ -737,7 +754,9 @@ int hc_set_option(hc_ctx *c, int option, int value)
     c->dbg_frames = 0;
   } else if (option == HC_OPT_PIPELINE) {
     HIPCK(hipSetDevice(c->device));
-    if (value && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;
+    if (value)
+      for (int k = 1; k < NSLOT; ++k)
+        if (alloc_slot(c, c->slot[k]) != HC_OK) return HC_E_HIP;
     c->pipeline = value != 0;
     c->cur = 0;
   } else return fail(HC_E_ARG, "hc_set_option: unknown option");
