@@ -33,7 +33,9 @@ constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0 .. MAX) launch flags, t
 
 // Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's hysteresis (pipelined
 // mode); the plain mode only uses slot 0.  (Three were measured: run i+1 then no longer waits for the hysteresis of run
-// i-1 -- no difference at 1080p in either mode, the two kernels share the device anyway.)
+// i-1 -- no difference at 1080p in either mode, at 4K, with BGR input or at 8K x 3: where the step is longer than the front
+// kernel, it is the hysteresis stream that is full -- its launch 0 runs starved beside the front kernel for as long as
+// that takes, the later launches follow -- and a third slot only lets it fall further behind.)
 constexpr int NSLOT = 2;
 struct Slot {
   u32 *d_sbits = nullptr, *d_cbits = nullptr;  // bit planes [max_batch][H][RD]
