@@ -1516,11 +1516,11 @@ static inline HystGeom hyst_geom(bool beside_front) { return beside_front ? Hyst
 void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, int *tile_rows, int *waves)
 {
   HystGeom g = hyst_geom(beside_front);
-  // taller frames, taller tiles: an edge that runs down the frame crosses a tile boundary per launch, and only 16 launches
-  // are queued per run (about 17 row tiles per frame at every size: 4K 97.3 k against 95.2 k frames/s, 8K x 3 channels
-  // 6.4 k against 5.1 k, where the 2-wave tiles needed a host-side continuation every step)
-  if (beside_front && H > 2400) g.waves = 8;
-  else if (beside_front && H > 1200) g.waves = 4;
+  // (Taller frames had taller tiles here -- 4 waves above 1200 rows, 8 above 2400 -- from the time when 16 launches were
+  // queued per run.  With up to 48 launches queued and the tile height following the content (queue_hyst_expand), the small
+  // 2-wave workgroups are as good at 4K (101 k frames/s either way) and better at 8K x 3 channels: 7.5 k against 6.6 k
+  // frames/s -- an 8-wave workgroup needs two free wave slots on every SIMD of a CU at once, and launch 0 ran starved
+  // beside the front kernel for as long as that took.)
   // a few frames only (the reference's one-frame-per-call pattern): the chip is nearly empty and the launches are pure
   // latency -- 8 waves x 16 rows per workgroup halve the rows a wave walks one after the other (measured on one 1080p
   // frame: hysteresis 0.122 ms against 0.139 ms with 8 x 32 and 0.130 ms with 4 x 32)

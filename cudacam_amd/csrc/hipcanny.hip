@@ -312,6 +312,10 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // still costs ~5 us of pure latency, so only what the last runs needed is queued, + 2; frames that need more are
   // finished by the host-side continuation (cheap here: nothing else is in flight).
   if (!small_tiles && (long)n * c->H < 128 * 1024 && c->hyst_need_rows > 0) K = std::min(K, std::max(4, need + 2));
+  // ... and in a pipelined stream whose needs are known, not the worst case of an edge down the whole frame (68 row tiles
+  // at 8K: 48 launches queued, 30 of them idle at ~5 us each on the hysteresis stream) but what the last runs needed, + 4;
+  // a frame that needs more is finished by the continuation, and the estimate follows it at once
+  if (small_tiles && c->hyst_need_rows > 0) K = std::min(K, std::max(6, need + 4));
   if (c->hyst_launches_set) K = c->hyst_launches;
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   hp.first_pass = 1;
