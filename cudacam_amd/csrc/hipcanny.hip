@@ -28,7 +28,7 @@ int fail(int code, const std::string &msg)
   } while (0)
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-constexpr int MAX_HYST_LAUNCHES = 48;
+constexpr int MAX_HYST_LAUNCHES = 96;  // (48 until a weak edge wobbling along a tile boundary needed 52: one launch per crossing)
 constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0 .. MAX) launch flags, then 3 diagnostic words per launch
 
 // Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's hysteresis (pipelined
@@ -313,7 +313,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // finished by the host-side continuation (cheap here: nothing else is in flight).
   if (!small_tiles && (long)n * c->H < 128 * 1024 && c->hyst_need_rows > 0) K = std::min(K, std::max(4, need + 2));
   // ... and in a pipelined stream whose needs are known, not the worst case of an edge down the whole frame (68 row tiles
-  // at 8K: 48 launches queued, 30 of them idle at ~5 us each on the hysteresis stream) but what the last runs needed, + 4;
+  // at 8K: 70 launches queued, 50 of them idle at ~5 us each on the hysteresis stream) but what the last runs needed, + 4;
   // a frame that needs more is finished by the continuation, and the estimate follows it at once
   if (small_tiles && c->hyst_need_rows > 0) K = std::min(K, std::max(6, need + 4));
   if (c->hyst_launches_set) K = c->hyst_launches;
@@ -722,7 +722,7 @@ int hc_set_tuning(hc_ctx *c, int chunk_rows, int hyst_launches)
 {
   if (!c) return fail(HC_E_ARG, "null context");
   if (chunk_rows < 0 || chunk_rows > 16384) return fail(HC_E_ARG, "chunk_rows must be 0 (auto) or 1..16384");
-  if (hyst_launches < 0 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range (0 = auto, 1..48)");
+  if (hyst_launches < 0 || hyst_launches > MAX_HYST_LAUNCHES) return fail(HC_E_ARG, "hyst_launches out of range (0 = auto, 1..96)");
   if (int rc = finish_all(c)) return rc;
   c->chunk = chunk_rows;
   c->hyst_launches_set = hyst_launches != 0;

@@ -137,7 +137,8 @@ int hc_last_run_info(hc_ctx *ctx, int *input_staged, int *output_staged, int *fr
 int hc_hysteresis_stats(hc_ctx *ctx, unsigned *stats, int nwords);
 
 /* Tuning knobs: rows per front-path work item (0 = auto); hysteresis launches queued per run (0 = auto:
- * 6, or one more than the row tiles + column panels of a frame, at most 48; launches after convergence exit at once, and
+ * 6, or one more than the row tiles + column panels of a frame, or what the last runs needed + 4, at most 96; launches
+ * after convergence exit at once, and
  * hc_sync continues from the host in the rare case the queue was too short -- non-monotone, serpentine edges). */
 int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
 
