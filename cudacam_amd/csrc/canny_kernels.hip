@@ -1531,43 +1531,51 @@ void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, 
 }
 
 // PANELS: the frame is wider than one 2048-column panel (tiles then also have left / right neighbours); the common
-// narrower case is compiled without that code
-template <int NW, int TR, int WAVES, bool PANELS>
-__global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
+// narrower case is compiled without that code.
+// One workgroup tile, gtile = frame * tiles per frame + tile.  How launches >= 1 find the tiles with work (k_hyst below):
+// MODE 0: every launch starts a workgroup per tile, and a tile looks at the change flags its neighbours left in the
+//         previous launch (p.tflags); launch index at run time (p.iter).
+// MODE 1: launch 0 of the worklist scheme -- every tile, every row open; tiles that change a boundary append the
+//         neighbours that look at it to the next launch's list.
+// MODE 2: a later launch of the worklist scheme; the tile is on the list because a neighbour above / below / beside
+//         changed the row or column it looks at (top / bot / side).
+template <int NW, int TR, int WAVES, bool PANELS, int MODE>
+static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile, bool top, bool bot, bool side)
 {
+  const bool LATE = MODE == 0 ? p.iter > 0 : MODE == 2;
   static_assert(NW == 1, "frames wider than one panel are tiled in column panels; a lane holds one dword per row");
   static_assert((TR & (TR - 1)) == 0, "row indices are wrapped with TR - 1");
-  if (p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
-  // latency-bound kernel (a few waves walking dependent row steps): when it shares a SIMD with the next
-  // run's front waves (pipelined mode) it should win the instruction arbitration
-  __builtin_amdgcn_s_setprio(3);
   constexpr int ROWW = 64 * NW;  // dwords per row
   constexpr int BR = WAVES * TR;
+  constexpr int XQ_CAP = 256;  // a row adds up to 128 groups to a queue holding fewer than 64
   __shared__ u32 edge[(2 * WAVES + 2) * ROWW];  // per wave: first and last row of S; then the two halo rows
   __shared__ u32 bchg[24];
-  constexpr int XQ_CAP = 256;  // a row adds up to 128 groups to a queue holding fewer than 64
   __shared__ u32 xqueue[WAVES * XQ_CAP];
   const int lane = threadIdx.x & 63, wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // tiles are 2-D: row tile bt x column panel pn (a panel = ROWW dwords = 2048 columns; frames up to 2048
   // columns have one panel).  A wave always holds one dword per lane and row, whatever the frame width.
   const int NP = PANELS ? p.npanels : 1, ntile = p.nrtiles * NP;
-  const int tile = blockIdx.x % ntile, frame = blockIdx.x / ntile;
+  const int tile = gtile % ntile, frame = gtile / ntile;
   const int bt = tile / NP, pn = tile % NP;
   const int H = p.H, RD = p.RD;
   const int pcol = pn * ROWW;                          // first dword of this panel in a plane row
   const int b0 = bt * BR, nb = min(H, b0 + BR) - b0;  // rows of this workgroup tile
-  uint8_t *tf_prev = p.tflags + (size_t)((p.iter + 1) & 1) * p.nframes * ntile + (size_t)frame * ntile;
-  uint8_t *tf_cur = p.tflags + (size_t)(p.iter & 1) * p.nframes * ntile + (size_t)frame * ntile;
-  // tile flags: 1 first row changed, 2 last row changed, 4 first column changed, 8 last column changed
-  bool top = false, bot = false, side = false;
-  if (p.iter > 0) {
-    // work only if a neighbouring tile changed the row / column / corner this tile looks at
-    auto flag = [&](int t, int q) -> int { return (t >= 0 && t < p.nrtiles && q >= 0 && q < NP) ? __builtin_amdgcn_readfirstlane(tf_prev[t * NP + q]) : 0; };
-    top = ((flag(bt - 1, pn) | flag(bt - 1, pn - 1) | flag(bt - 1, pn + 1)) & 2) != 0;
-    bot = ((flag(bt + 1, pn) | flag(bt + 1, pn - 1) | flag(bt + 1, pn + 1)) & 1) != 0;
-    side = (flag(bt, pn - 1) & 8) != 0 || (flag(bt, pn + 1) & 4) != 0;
-    if (!top && !bot && !side) {  // uniform for the workgroup
-      if (threadIdx.x == 0) tf_cur[tile] = 0;
+  uint8_t *tf_cur = nullptr;
+  if (MODE == 0) {
+    // tile flags: 1 first row changed, 2 last row changed, 4 first column changed, 8 last column changed
+    const uint8_t *tf_prev = p.tflags + (size_t)((p.iter + 1) & 1) * p.nframes * ntile + (size_t)frame * ntile;
+    tf_cur = p.tflags + (size_t)(p.iter & 1) * p.nframes * ntile + (size_t)frame * ntile;
+    if (LATE) {
+      // work only if a neighbouring tile changed the row / column / corner this tile looks at
+      auto flag = [&](int t, int q) -> int { return (t >= 0 && t < p.nrtiles && q >= 0 && q < NP) ? __builtin_amdgcn_readfirstlane(tf_prev[t * NP + q]) : 0; };
+      top = ((flag(bt - 1, pn) | flag(bt - 1, pn - 1) | flag(bt - 1, pn + 1)) & 2) != 0;
+      bot = ((flag(bt + 1, pn) | flag(bt + 1, pn - 1) | flag(bt + 1, pn + 1)) & 1) != 0;
+      side = (flag(bt, pn - 1) & 8) != 0 || (flag(bt, pn + 1) & 4) != 0;
+    }
+  }
+  if (LATE) {
+    if (!top && !bot && !side) {  // uniform for the workgroup (worklist scheme: not on a list without a reason)
+      if (MODE == 0 && threadIdx.x == 0) tf_cur[tile] = 0;
       return;
     }
     // A neighbour's boundary row changed somewhere -- but does a new bit reach a candidate of this tile?  Only
@@ -1593,7 +1601,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
       if (hit && lane == 0) atomicOr(&bchg[20], 1u);
       __syncthreads();
       if (__builtin_amdgcn_readfirstlane(bchg[20]) == 0) {
-        if (threadIdx.x == 0) tf_cur[tile] = 0;
+        if (MODE == 0 && threadIdx.x == 0) tf_cur[tile] = 0;
         return;
       }
     }
@@ -1603,7 +1611,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   const bool owns_last = n > 0 && w0 + n == nb;
   const u64 all_rows = n >= 64 ? ~0ull : ((1ull << n) - 1);
   u64 dirty;  // bit r = row b0 + w0 + r needs (re)evaluation
-  if (p.iter > 0) dirty = side ? all_rows : (((top && w0 == 0 && n > 0) ? 1ull : 0ull) | ((bot && owns_last) ? (1ull << (n - 1)) : 0ull));
+  if (LATE) dirty = side ? all_rows : (((top && w0 == 0 && n > 0) ? 1ull : 0ull) | ((bot && owns_last) ? (1ull << (n - 1)) : 0ull));
   else dirty = all_rows;
   dirty = uniform64(dirty);
   u64 unfilled = p.first_pass ? all_rows : 0ull;  // rows not yet closed under the in-row fill
@@ -1697,7 +1705,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   // (no s_set_gpr_idx, no dependency between them); every other row is only visited if a neighbour changes later.
   // (Two unrolled sequential sweeps with compile-time registers were tried instead: 63 inlined row updates are 76 KB of
   // code, the instruction cache misses made the hysteresis 1.9x slower.)
-  if (NW == 1 && p.iter == 0 && n == TR) {
+  if (NW == 1 && !LATE && n == TR) {
     u64 act = 0;
     auto test_row = [&](auto self, auto rc) {
       constexpr int r = decltype(rc)::value;
@@ -1808,7 +1816,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   // expanded row by row (a few active lanes per instruction) but collected in a wave-private LDS queue -- one dword
   // per group: its 16 bits, row and position -- and expanded 64 at a time, a group per lane.
   {
-    const bool patch = p.out && (p.iter > 0 || p.prov);
+    const bool patch = p.out && (LATE || p.prov);
     const bool a16 = (((uintptr_t)p.out | p.out_pitch | p.out_frame_stride) & 15u) == 0;
     uint8_t *obase = p.out ? p.out + (size_t)frame * p.out_frame_stride : nullptr;
     u32 *Sw = S + (size_t)(b0 + w0) * RD;  // the wave's first row (uniform); this lane's dword is at pcol + lane
@@ -1826,7 +1834,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 #pragma unroll
           for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
       } else {
-        for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+#pragma nounroll  // (unrolled, the 16 exec masks of this ragged last group cost the kernel an SGPR spill, i.e. a VGPR: 81 instead of 80)
+        for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = ((b >> k) & 1u) ? (uint8_t)255 : (uint8_t)0;
       }
     };
     u32 *xq = xqueue + wib * XQ_CAP;  // ring of changed groups: bits | row (6 bits) << 16 | group-of-the-panel-row << 22
@@ -1860,7 +1869,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 #pragma unroll
               for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
           } else {
-            for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = (uint8_t)(v[k >> 2] >> (8 * (k & 3)));
+#pragma nounroll  // (unrolled, the 16 exec masks of this ragged last group cost the kernel an SGPR spill, i.e. a VGPR: 81 instead of 80)
+            for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = ((b >> k) & 1u) ? (uint8_t)255 : (uint8_t)0;
           }
         }
       }
@@ -1914,10 +1924,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   const bool last_changed = owns_last && ((changed >> (n - 1)) & 1ull);
   if (lane == 0 && (first_changed || last_changed || colchg)) atomicOr(&bchg[16], (first_changed ? 1u : 0u) | (last_changed ? 2u : 0u) | (colchg << 2));
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (MODE == 0) {
+    if (threadIdx.x == 0) {
+      const u32 vis = bchg[16];
+      tf_cur[tile] = (uint8_t)vis;
+      if (vis) atomicOr(&p.flags[p.iter], 1u);
+    }
+  } else if (wib == 0) {
+    // The neighbours that look at what changed go on the next launch's worklist -- once each: the first reason to arrive
+    // appends the tile, later ones only add their bit.  One lane per neighbour, so that the atomics' round trips overlap.
     const u32 vis = bchg[16];
-    tf_cur[tile] = (uint8_t)vis;
-    if (vis) atomicOr(&p.flags[p.iter], 1u);
+    if (vis != 0) {
+      if (lane == 0) atomicOr(&p.flags[p.iter], 1u);
+      const int nxt = (p.iter + 1) & 1;
+      u32 *reason = p.wl_reason + (size_t)nxt * p.wl_stride, *list = p.wl_list + (size_t)nxt * p.wl_stride;
+      // lanes 0-2: the tiles below (my last row changed: their `top`), 3-5: above (my first row: their `bot`), 6 / 7: the
+      // panel left / right (my first / last column: their `side`)
+      const int k = lane;
+      const int t = k < 3 ? bt + 1 : k < 6 ? bt - 1 : bt;
+      const int q = k < 6 ? pn + (k % 3) - 1 : (k == 6 ? pn - 1 : pn + 1);
+      const u32 need = k < 3 ? 2u : k < 6 ? 1u : k == 6 ? 4u : 8u;
+      const u32 why = k < 3 ? 1u : k < 6 ? 2u : 4u;
+      if (k < 8 && (vis & need) != 0 && t >= 0 && t < p.nrtiles && q >= 0 && q < NP) {
+        const u32 g = (u32)(frame * ntile + t * NP + q);
+        if (atomicOr(&reason[g], why) == 0) list[atomicAdd(&p.wl_count[p.iter + 1], 1u)] = g;
+      }
+    }
   }
   if (lane == 0 && p.stats && n > 0) {  // diagnostics (opt-in): changed rows summed / max over wave tiles, active wave tiles
     const u32 nch = (u32)__builtin_popcountll(changed);
@@ -1927,17 +1959,76 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   }
 }
 
+// MODE 0 (frames of one column panel, up to 2048 columns): a workgroup per tile in every launch; a tile whose neighbours
+// left no change flag exits after three byte loads.
+// MODE 1 / 2 (wider frames): launch 0 as above; launch k > 0 takes its tiles from the worklist its predecessor wrote --
+// the tiles whose neighbours changed a boundary row / column -- with a grid that is a fraction of the tile count
+// (launch_hyst), one list entry per workgroup.  With panels a tile has eight neighbours, the flag test of MODE 0 is nine
+// dependent byte loads, and the late launches that follow the few long edges of a frame through its tiles each started
+// 17 k workgroups to find 1-2 % of them with work: on 4K and 8K streams most of the hysteresis chain's time, which is
+// what their step follows (4K 100 -> 108 k frames/s, 8K x 3 channels 7.4 -> 8.3 k, 8K grey 15.8 -> 19.7 k).  At 1080p
+// the flags are better: 388 k against 378 k frames/s -- there the step follows the front kernel, and a hysteresis that
+// is spread thinly over it costs it less than the same work done in two thirds of the time (1.64 against 2.27 ms).
+// No loop over list entries: around the tile code it costs registers (85-91 VGPRs; 148 and a stack as a real function),
+// and the tile code must stay at 80 -- two hysteresis waves per 160-register hole a retiring front wave leaves.  Entries
+// beyond the grid (dense or adversarial content: more than the grid's share of the tiles still active) are handed on to
+// the next launch's list instead.
+template <int NW, int TR, int WAVES, bool PANELS, int MODE>
+__global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
+{
+  if (MODE == 0 && p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
+  // latency-bound kernel (a few waves walking dependent row steps): when it shares a SIMD with the next
+  // run's front waves (pipelined mode) it should win the instruction arbitration
+  __builtin_amdgcn_s_setprio(3);
+  if constexpr (MODE != 2) {
+    hyst_tile<NW, TR, WAVES, PANELS, MODE>(p, (int)blockIdx.x, false, false, false);
+  } else {
+    const u32 cnt = p.wl_count[p.iter];  // 0: the previous launch changed no tile boundary, the fixpoint is reached
+    if (blockIdx.x >= cnt) return;
+    const u32 *list = p.wl_list + (size_t)(p.iter & 1) * p.wl_stride;
+    u32 *reason = p.wl_reason + (size_t)(p.iter & 1) * p.wl_stride;
+    if (cnt > gridDim.x && threadIdx.x == 0 && blockIdx.x + gridDim.x < cnt) {
+      const int nxt = (p.iter + 1) & 1;
+      u32 *reason_n = p.wl_reason + (size_t)nxt * p.wl_stride, *list_n = p.wl_list + (size_t)nxt * p.wl_stride;
+      for (u32 j = blockIdx.x + gridDim.x; j < cnt; j += gridDim.x) {
+        const u32 g2 = list[j], w2 = reason[g2];
+        reason[g2] = 0;
+        if (atomicOr(&reason_n[g2], w2) == 0) list_n[atomicAdd(&p.wl_count[p.iter + 1], 1u)] = g2;
+      }
+      atomicOr(&p.flags[p.iter], 1u);  // work is left for another launch
+    }
+    const u32 g = (u32)__builtin_amdgcn_readfirstlane((int)list[blockIdx.x]);
+    const u32 why = (u32)__builtin_amdgcn_readfirstlane((int)reason[g]);
+    __syncthreads();  // everyone has the reason before it is cleared for launch k + 2
+    if (threadIdx.x == 0) reason[g] = 0;
+    hyst_tile<NW, TR, WAVES, PANELS, 2>(p, (int)g, (why & 1u) != 0, (why & 2u) != 0, (why & 4u) != 0);
+  }
+}
+
 hipError_t launch_hyst(const HystParams &p, hipStream_t s)
 {
   const HystGeom g = { 1, p.tile_rows, p.waves };
   if (p.RD > 256) return hipErrorInvalidValue;
   if (p.npanels != (p.RD + 63) / 64 || p.RD % 64) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)(p.nframes * p.nrtiles * p.npanels)), block(64 * g.waves);
-  const bool wide = p.npanels > 1;
-#define HC_HYST_LAUNCH(TR_, WAVES_)                                                         \
-  {                                                                                          \
-    if (wide) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true>), grid, block, 0, s, p);      \
-    else hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, false>), grid, block, 0, s, p);          \
+  const size_t tiles = (size_t)p.nframes * p.nrtiles * p.npanels;
+  const bool wide = p.npanels > 1, late = p.iter > 0;
+  if (!p.tflags || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
+  if (wide && (!p.wl_count || !p.wl_reason || !p.wl_list || p.wl_stride < tiles)) return hipErrorInvalidValue;
+  // a workgroup per tile -- except the later launches of wide frames: a workgroup per worklist entry, with a grid that
+  // shrinks to an eighth of the tiles (at least 2048 workgroups): on camera-like frames a third of the tiles are listed
+  // for launch 1, 1-2 % from launch 5 on; entries beyond the grid wait for the next launch (k_hyst).  p.late_grid
+  // (diagnostics) fixes the grid.
+  size_t wgs = tiles;
+  if (wide && late) {
+    wgs = std::min(tiles, std::max<size_t>(2048, tiles >> std::min(std::max(p.iter - 2, 0), 3)));
+    if (p.late_grid > 0) wgs = std::min(tiles, (size_t)p.late_grid);
+  }
+  const dim3 grid((unsigned)wgs), block(64 * g.waves);
+#define HC_HYST_LAUNCH(TR_, WAVES_)                                                                 \
+  {                                                                                                  \
+    if (wide && late) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 2>), grid, block, 0, s, p);   \
+    else if (wide) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 1>), grid, block, 0, s, p);      \
+    else hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, false, 0>), grid, block, 0, s, p);               \
   }
   if (g.nw == 1 && g.tr == 32 && g.waves == 8) HC_HYST_LAUNCH(32, 8)
   else if (g.nw == 1 && g.tr == 32 && g.waves == 4) HC_HYST_LAUNCH(32, 4)

@@ -30,6 +30,10 @@ int fail(int code, const std::string &msg)
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 constexpr int MAX_HYST_LAUNCHES = 96;  // (48 until a weak edge wobbling along a tile boundary needed 52: one launch per crossing)
 constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0 .. MAX) launch flags, then 3 diagnostic words per launch
+// d_flags continues with what must also be zero when a run starts (one memset): the worklist counts of the hysteresis
+// launches, then the per-tile reason words of both launch parities (HystParams::wl_count / wl_reason)
+constexpr int WL_COUNT_WORDS = 128;
+static_assert(WL_COUNT_WORDS >= MAX_HYST_LAUNCHES + 1, "a count per launch and one beyond the last");
 
 // Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's hysteresis (pipelined
 // mode); the plain mode only uses slot 0.  (Three were measured: run i+1 then no longer waits for the hysteresis of run
@@ -39,7 +43,9 @@ constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0 .. MAX) launch flags, t
 constexpr int NSLOT = 2;
 struct Slot {
   u32 *d_sbits = nullptr, *d_cbits = nullptr;  // bit planes [max_batch][H][RD]
-  uint8_t *d_tflags = nullptr;
+  uint8_t *d_tflags = nullptr;  // hysteresis tile change flags (HystParams::tflags)
+  u32 *d_wl_list = nullptr;  // hysteresis worklists (HystParams::wl_list)
+  size_t wl_cap = 0;         // tiles a run can have
   u32 *d_flags = nullptr, *h_flags = nullptr;
   hipEvent_t ev_front = nullptr, ev_done = nullptr;  // front kernel finished / hysteresis + expand finished
   bool pending = false;                              // convergence flag not yet checked by the host
@@ -71,6 +77,9 @@ struct hc_ctx {
   int cur = 0;
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
+  u32 wl_prev[MAX_HYST_LAUNCHES + 1] = { 0 };  // worklist lengths of the last finished run's launches
+  size_t wl_prev_tiles = 0;                    // ... and its tile count (0: none / not a wide-frame run)
+  int hyst_late_grid = 0;              // diagnostics (HC_HYST_LATE_GRID): workgroups of the hysteresis launches >= 1
   int hyst_rows_last = 0;              // rows per wave of the last run's hysteresis tiles
   int hyst_waves_last = 0;             // waves per hysteresis workgroup of the last run (adaptive tile height, queue_hyst_expand)
   bool hyst_waves_last_small = false;  // ... and whether that run was a pipelined one (different base shape)
@@ -148,9 +157,12 @@ int alloc_slot(hc_ctx *c, Slot &s)
   // row padding beyond the strips' bytes is never written by the kernels and must read as 0
   HIPCK(hipMemset(s.d_sbits, 0, plane_bytes));
   HIPCK(hipMemset(s.d_cbits, 0, plane_bytes));
-  HIPCK(hipMalloc((void **)&s.d_tflags, (size_t)2 * out_frames * ((size_t)(c->H + 7) / 8 + 1) * ((c->RD + 63) / 64)));
-  HIPCK(hipMalloc((void **)&s.d_flags, sizeof(u32) * FLAG_WORDS));
-  HIPCK(hipHostMalloc((void **)&s.h_flags, sizeof(u32) * FLAG_WORDS, hipHostMallocDefault));
+  // tiles of a run: at most out_frames x row tiles (16 rows or more each) x column panels
+  s.wl_cap = out_frames * ((size_t)(c->H + 15) / 16 + 1) * ((c->RD + 63) / 64);
+  HIPCK(hipMalloc((void **)&s.d_wl_list, sizeof(u32) * 2 * s.wl_cap));
+  HIPCK(hipMalloc((void **)&s.d_tflags, 2 * s.wl_cap));
+  HIPCK(hipMalloc((void **)&s.d_flags, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * s.wl_cap)));
+  HIPCK(hipHostMalloc((void **)&s.h_flags, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS), hipHostMallocDefault));
   HIPCK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
   HIPCK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
   return HC_OK;
@@ -158,7 +170,7 @@ int alloc_slot(hc_ctx *c, Slot &s)
 
 void free_slot(Slot &s)
 {
-  for (void *q : { (void *)s.d_sbits, (void *)s.d_cbits, (void *)s.d_tflags, (void *)s.d_flags }) (void)hipFree(q);
+  for (void *q : { (void *)s.d_sbits, (void *)s.d_cbits, (void *)s.d_wl_list, (void *)s.d_tflags, (void *)s.d_flags }) (void)hipFree(q);
   if (s.h_flags) (void)hipHostFree(s.h_flags);
   if (s.ev_front) (void)hipEventDestroy(s.ev_front);
   if (s.ev_done) (void)hipEventDestroy(s.ev_done);
@@ -247,12 +259,15 @@ int finish_slot(hc_ctx *c, Slot &s)
   std::memcpy(c->h_stats, s.h_flags + MAX_HYST_LAUNCHES, sizeof(c->h_stats));
   c->last_work_launches = std::min(K, work + 1);
   c->last_continued = 0;
+  // worklist lengths of this run's launches (wide frames): the next run of the same shape sizes its grids by them
+  c->wl_prev_tiles = s.ph.npanels > 1 ? s.ph.wl_stride : 0;
+  for (int k = 0; k <= MAX_HYST_LAUNCHES; ++k) c->wl_prev[k] = s.h_flags[FLAG_WORDS + k];
   const int tile = s.ph.tile_rows * s.ph.waves;
   c->hyst_need_rows = std::max(c->last_work_launches * tile, c->hyst_need_rows - 32);  // follows the content up at once, down slowly
   if (s.h_flags[K - 1] == 0) return HC_OK;
   c->last_continued = 1;
   for (int round = 0; round < 1000000; ++round) {
-    HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * FLAG_WORDS, st));
+    HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * s.ph.wl_stride), st));  // flags, worklist counts and reasons
     HystParams hp = s.ph;
     hp.first_pass = 0;
     hp.stats = nullptr;
@@ -260,7 +275,7 @@ int finish_slot(hc_ctx *c, Slot &s)
       hp.iter = k;
       HIPCK(launch_hyst(hp, st));
     }
-    HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, st));
+    HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS), hipMemcpyDeviceToHost, st));
     HIPCK(hipStreamSynchronize(st));
     for (int k = 0; k < K; ++k) c->last_work_launches += s.h_flags[k] != 0;
     if (s.h_flags[K - 1] == 0) break;
@@ -318,15 +333,27 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   if (small_tiles && c->hyst_need_rows > 0) K = std::min(K, std::max(6, need + 4));
   if (c->hyst_launches_set) K = c->hyst_launches;
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
+  // worklists of launches >= 1: counts and reason words live behind the launch flags and are zeroed with them
+  hp.wl_stride = (size_t)n * hp.nrtiles * hp.npanels;
+  if (hp.wl_stride > s.wl_cap) return fail(HC_E_ARG, "internal: hysteresis worklist capacity");
+  hp.wl_count = s.d_flags + FLAG_WORDS;
+  hp.wl_reason = s.d_flags + FLAG_WORDS + WL_COUNT_WORDS;
+  hp.wl_list = s.d_wl_list;
+  HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * hp.wl_stride), st));
   hp.first_pass = 1;
   hp.prov = s.prov ? 1 : 0;
   for (int k = 0; k < K; ++k) {
     hp.iter = k;
+    // wide frames, launches >= 1: a workgroup per worklist entry.  Grid: twice what the last run of this shape listed for
+    // the launch (entries beyond the grid wait a launch: a dense frame would need several launches more); without such
+    // a run, launch_hyst's schedule by the tile count
+    hp.late_grid = c->hyst_late_grid;
+    if (!hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>(2048, 2 * (size_t)c->wl_prev[k] + 256));
     // diagnostics cost ~3 same-address atomics per wave (hundreds of microseconds per launch): opt-in only
     hp.stats = c->hyst_diag ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
     HIPCK(launch_hyst(hp, st));
   }
-  HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * FLAG_WORDS, hipMemcpyDeviceToHost, st));
+  HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS), hipMemcpyDeviceToHost, st));
   s.pending = true;
   s.k_launches = K;
   s.ph = hp;
@@ -542,7 +569,6 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       HIPCK(hipEventRecord(s.ev_front, sf));
       HIPCK(hipStreamWaitEvent(sh, s.ev_front, 0));
     }
-    HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * FLAG_WORDS, sh));
     if (int rc = queue_hyst_expand(c, s, sh, dst, dp, dfs, n_out, piped)) return rc;
   } else if (stage > HC_STAGE_MONO) {
     if (int rc = ensure_stage_scratch(c)) return rc;
@@ -645,6 +671,7 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   }
   c->stream = c->own_stream;
   c->hyst_diag = getenv("HC_HYST_DIAG") != nullptr;
+  if (const char *e = getenv("HC_HYST_LATE_GRID")) c->hyst_late_grid = std::max(0, atoi(e));  // tests: tiny grids exercise the hand-on of worklist entries
   if (const char *e = getenv("HC_HYST_GEOM")) {
     int tr = 0, wv = 0;
     if (sscanf(e, "%dx%d", &tr, &wv) == 2) c->hyst_geom = tr * 100 + wv;
@@ -814,7 +841,6 @@ int hc_hysteresis_device(hc_ctx *c, const void *d_thresh, size_t in_pitch, size_
   Slot &s = c->slot[0];
   PackParams pp{};
   pp.in = (const uint8_t *)d_thresh; pp.in_pitch = in_pitch; pp.in_frame_stride = in_fs; pp.sbits = s.d_sbits; pp.cbits = s.d_cbits; pp.RD = c->RD; pp.W = c->W; pp.H = c->H; pp.nframes = n;
-  HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * FLAG_WORDS, c->stream));
   HIPCK(launch_pack(pp, c->stream));
   uint8_t *dst = (uint8_t *)d_out;
   size_t dp = out_pitch, dfs = out_fs;
