@@ -61,14 +61,14 @@ struct HystParams {
   int nrtiles;     // row tiles per frame = ceil(H / (waves * tile_rows))
   int npanels;     // column panels per row tile = RD / 64 (a panel = 64 dwords = 2048 columns)
   u32 *flags;      // flags[k] != 0: launch k changed a tile-boundary row (another launch is needed)
-  uint8_t *tflags; // frames of one column panel: [2][nframes][nrtiles]: 1 first row, 2 last row changed (per launch parity)
-  // wider frames: worklists of launches >= 1 (launch 0 visits every tile): a tile that changes a boundary row / column appends the neighbours
-  // that look at it to the next launch's list.  [2] = launch parity; wl_stride >= nframes * nrtiles * npanels words.
-  u32 *wl_count;   // [launches + 1] tiles on the list of launch k; zero at the start of a run
+  // How launches >= 1 find the tiles with work: a tile that changes a boundary row / column leaves a reason word with the
+  // neighbours that look at it; wide frames also append them to the next launch's worklist.  [2] = launch parity;
+  // wl_stride >= nframes * nrtiles * npanels words.
+  u32 *wl_count;   // [launches + 1] wide frames: tiles on the list of (visited by) launch k; zero at the start of a run
   u32 *wl_reason;  // [2][wl_stride] per tile: 1 a tile above changed (its `top`), 2 below, 4 beside; zero at the start of a run
-  u32 *wl_list;    // [2][wl_stride] tile ids (frame * tiles per frame + tile)
+  u32 *wl_list;    // [2][wl_stride] wide frames: tile ids (frame * tiles per frame + tile)
   size_t wl_stride;
-  int late_grid;   // diagnostics: workgroups of launches >= 1 (0 = by the tile count, launch_hyst)
+  int late_grid;   // wide frames: workgroups of launches >= 1 (0 = by the tile count, launch_hyst; -1 = no worklists: MODE 0 of k_hyst)
   int iter;        // index of this launch
   u32 *stats;      // optional diagnostics (3 words per launch) or null
   // fused expand: every launch also writes the 0/255 u8 rows it owns (launch 0: all rows of the tile,

@@ -1533,8 +1533,8 @@ void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, 
 // PANELS: the frame is wider than one 2048-column panel (tiles then also have left / right neighbours); the common
 // narrower case is compiled without that code.
 // One workgroup tile, gtile = frame * tiles per frame + tile.  How launches >= 1 find the tiles with work (k_hyst below):
-// MODE 0: every launch starts a workgroup per tile, and a tile looks at the change flags its neighbours left in the
-//         previous launch (p.tflags); launch index at run time (p.iter).
+// MODE 0: every launch starts a workgroup per tile, and a tile looks at the reason word its neighbours left it in the
+//         previous launch (p.wl_reason); launch index at run time (p.iter).
 // MODE 1: launch 0 of the worklist scheme -- every tile, every row open; tiles that change a boundary append the
 //         neighbours that look at it to the next launch's list.
 // MODE 2: a later launch of the worklist scheme; the tile is on the list because a neighbour above / below / beside
@@ -1560,24 +1560,22 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
   const int H = p.H, RD = p.RD;
   const int pcol = pn * ROWW;                          // first dword of this panel in a plane row
   const int b0 = bt * BR, nb = min(H, b0 + BR) - b0;  // rows of this workgroup tile
-  uint8_t *tf_cur = nullptr;
-  if (MODE == 0) {
-    // tile flags: 1 first row changed, 2 last row changed, 4 first column changed, 8 last column changed
-    const uint8_t *tf_prev = p.tflags + (size_t)((p.iter + 1) & 1) * p.nframes * ntile + (size_t)frame * ntile;
-    tf_cur = p.tflags + (size_t)(p.iter & 1) * p.nframes * ntile + (size_t)frame * ntile;
-    if (LATE) {
-      // work only if a neighbouring tile changed the row / column / corner this tile looks at
-      auto flag = [&](int t, int q) -> int { return (t >= 0 && t < p.nrtiles && q >= 0 && q < NP) ? __builtin_amdgcn_readfirstlane(tf_prev[t * NP + q]) : 0; };
-      top = ((flag(bt - 1, pn) | flag(bt - 1, pn - 1) | flag(bt - 1, pn + 1)) & 2) != 0;
-      bot = ((flag(bt + 1, pn) | flag(bt + 1, pn - 1) | flag(bt + 1, pn + 1)) & 1) != 0;
-      side = (flag(bt, pn - 1) & 8) != 0 || (flag(bt, pn + 1) & 4) != 0;
+  if (MODE == 0 && LATE) {
+    // work only if a neighbouring tile changed the row / column / corner this tile looks at: it left its reason in this
+    // tile's word of the launch's parity (one load; cleared for the launch after next)
+    u32 *reason = p.wl_reason + (size_t)(p.iter & 1) * p.wl_stride;
+    const u32 why = (u32)__builtin_amdgcn_readfirstlane((int)reason[gtile]);
+    top = (why & 1u) != 0; bot = (why & 2u) != 0; side = (why & 4u) != 0;
+    if (why != 0) {
+      __syncthreads();  // (uniform branch) everyone has the reason before it is cleared
+      if (threadIdx.x == 0) {
+        reason[gtile] = 0;
+        if (PANELS) atomicAdd(&p.wl_count[p.iter], 1u);  // wide frames: how many tiles this launch visits (the host picks worklists or this form by it)
+      }
     }
   }
   if (LATE) {
-    if (!top && !bot && !side) {  // uniform for the workgroup (worklist scheme: not on a list without a reason)
-      if (MODE == 0 && threadIdx.x == 0) tf_cur[tile] = 0;
-      return;
-    }
+    if (!top && !bot && !side) return;  // uniform for the workgroup
     // A neighbour's boundary row changed somewhere -- but does a new bit reach a candidate of this tile?  Only
     // then can anything change here (the tile is at its own fixpoint).  Checked on the two boundary rows alone
     // (4 row loads) before the 2 x TR rows per wave are fetched: most tiles leave here in launches >= 1.
@@ -1600,10 +1598,7 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
       __syncthreads();
       if (hit && lane == 0) atomicOr(&bchg[20], 1u);
       __syncthreads();
-      if (__builtin_amdgcn_readfirstlane(bchg[20]) == 0) {
-        if (MODE == 0 && threadIdx.x == 0) tf_cur[tile] = 0;
-        return;
-      }
+      if (__builtin_amdgcn_readfirstlane(bchg[20]) == 0) return;
     }
   }
   // this wave's rows inside the workgroup tile
@@ -1925,10 +1920,20 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
   if (lane == 0 && (first_changed || last_changed || colchg)) atomicOr(&bchg[16], (first_changed ? 1u : 0u) | (last_changed ? 2u : 0u) | (colchg << 2));
   __syncthreads();
   if (MODE == 0) {
-    if (threadIdx.x == 0) {
+    // the tiles that look at what changed get their reason (no list: every launch starts a workgroup per tile, and a tile
+    // without a reason leaves after one load).  One lane per neighbour, as below.
+    if (wib == 0) {
       const u32 vis = bchg[16];
-      tf_cur[tile] = (uint8_t)vis;
-      if (vis) atomicOr(&p.flags[p.iter], 1u);
+      if (vis != 0) {
+        if (lane == 0) atomicOr(&p.flags[p.iter], 1u);
+        u32 *reason = p.wl_reason + (size_t)((p.iter + 1) & 1) * p.wl_stride;
+        const int k = lane;
+        const int t = k < 3 ? bt + 1 : k < 6 ? bt - 1 : bt;
+        const int q = k < 6 ? pn + (k % 3) - 1 : (k == 6 ? pn - 1 : pn + 1);
+        const u32 need = k < 3 ? 2u : k < 6 ? 1u : k == 6 ? 4u : 8u;
+        const u32 why = k < 3 ? 1u : k < 6 ? 2u : 4u;
+        if (k < 8 && (vis & need) != 0 && t >= 0 && t < p.nrtiles && q >= 0 && q < NP) atomicOr(&reason[frame * ntile + t * NP + q], why);
+      }
     }
   } else if (wib == 0) {
     // The neighbours that look at what changed go on the next launch's worklist -- once each: the first reason to arrive
@@ -1959,8 +1964,8 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
   }
 }
 
-// MODE 0 (frames of one column panel, up to 2048 columns): a workgroup per tile in every launch; a tile whose neighbours
-// left no change flag exits after three byte loads.
+// MODE 0 (frames of one column panel, up to 2048 columns; dense wide frames): a workgroup per tile in every launch; a
+// tile whose neighbours left it no reason exits after one load.
 // MODE 1 / 2 (wider frames): launch 0 as above; launch k > 0 takes its tiles from the worklist its predecessor wrote --
 // the tiles whose neighbours changed a boundary row / column -- with a grid that is a fraction of the tile count
 // (launch_hyst), one list entry per workgroup.  With panels a tile has eight neighbours, the flag test of MODE 0 is nine
@@ -2012,8 +2017,8 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   if (p.npanels != (p.RD + 63) / 64 || p.RD % 64) return hipErrorInvalidValue;
   const size_t tiles = (size_t)p.nframes * p.nrtiles * p.npanels;
   const bool wide = p.npanels > 1, late = p.iter > 0;
-  if (!p.tflags || tiles > 0x7FFFFFFFull) return hipErrorInvalidValue;
-  if (wide && (!p.wl_count || !p.wl_reason || !p.wl_list || p.wl_stride < tiles)) return hipErrorInvalidValue;
+  if (tiles > 0x7FFFFFFFull || !p.wl_reason || p.wl_stride < tiles) return hipErrorInvalidValue;
+  if (wide && (!p.wl_count || !p.wl_list)) return hipErrorInvalidValue;
   // a workgroup per tile -- except the later launches of wide frames: a workgroup per worklist entry, with a grid that
   // shrinks to an eighth of the tiles (at least 2048 workgroups): on camera-like frames a third of the tiles are listed
   // for launch 1, 1-2 % from launch 5 on; entries beyond the grid wait for the next launch (k_hyst).  p.late_grid
@@ -2026,7 +2031,8 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   const dim3 grid((unsigned)wgs), block(64 * g.waves);
 #define HC_HYST_LAUNCH(TR_, WAVES_)                                                                 \
   {                                                                                                  \
-    if (wide && late) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 2>), grid, block, 0, s, p);   \
+    if (wide && p.late_grid < 0) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 0>), dim3((unsigned)tiles), block, 0, s, p);        \
+    else if (wide && late) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 2>), grid, block, 0, s, p);   \
     else if (wide) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 1>), grid, block, 0, s, p);      \
     else hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, false, 0>), grid, block, 0, s, p);               \
   }
