@@ -68,7 +68,8 @@ struct HystParams {
   u32 *wl_reason;  // [2][wl_stride] per tile: 1 a tile above changed (its `top`), 2 below, 4 beside; zero at the start of a run
   u32 *wl_list;    // [2][wl_stride] wide frames: tile ids (frame * tiles per frame + tile)
   size_t wl_stride;
-  int late_grid;   // wide frames: workgroups of launches >= 1 (0 = by the tile count, launch_hyst; -1 = no worklists: MODE 0 of k_hyst)
+  int lists;       // 1: launches >= 1 take their tiles from the worklists (k_hyst MODE 1 / 2); 0: a workgroup per tile in every launch (MODE 0)
+  int late_grid;   // worklist scheme: workgroups of launches >= 1 (0 = by the tile count, launch_hyst)
   int iter;        // index of this launch
   u32 *stats;      // optional diagnostics (3 words per launch) or null
   // fused expand: every launch also writes the 0/255 u8 rows it owns (launch 0: all rows of the tile,

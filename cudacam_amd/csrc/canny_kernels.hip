@@ -2016,25 +2016,29 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   if (p.RD > 256) return hipErrorInvalidValue;
   if (p.npanels != (p.RD + 63) / 64 || p.RD % 64) return hipErrorInvalidValue;
   const size_t tiles = (size_t)p.nframes * p.nrtiles * p.npanels;
-  const bool wide = p.npanels > 1, late = p.iter > 0;
+  const bool wide = p.npanels > 1, late = p.iter > 0, lists = p.lists != 0;
   if (tiles > 0x7FFFFFFFull || !p.wl_reason || p.wl_stride < tiles) return hipErrorInvalidValue;
-  if (wide && (!p.wl_count || !p.wl_list)) return hipErrorInvalidValue;
-  // a workgroup per tile -- except the later launches of wide frames: a workgroup per worklist entry, with a grid that
-  // shrinks to an eighth of the tiles (at least 2048 workgroups): on camera-like frames a third of the tiles are listed
-  // for launch 1, 1-2 % from launch 5 on; entries beyond the grid wait for the next launch (k_hyst).  p.late_grid
-  // (diagnostics) fixes the grid.
+  if ((wide || lists) && (!p.wl_count || !p.wl_list)) return hipErrorInvalidValue;
+  // a workgroup per tile -- except the later launches of the worklist scheme: a workgroup per list entry.  Grid: the
+  // caller's (p.late_grid, from the last run's list lengths), or a schedule that shrinks to an eighth of the tiles (at
+  // least 2048 workgroups): on camera-like frames a third of the tiles are listed for launch 1, 1-2 % from launch 5 on;
+  // entries beyond the grid wait for the next launch (k_hyst).
   size_t wgs = tiles;
-  if (wide && late) {
+  if (lists && late) {
     wgs = std::min(tiles, std::max<size_t>(2048, tiles >> std::min(std::max(p.iter - 2, 0), 3)));
     if (p.late_grid > 0) wgs = std::min(tiles, (size_t)p.late_grid);
   }
   const dim3 grid((unsigned)wgs), block(64 * g.waves);
-#define HC_HYST_LAUNCH(TR_, WAVES_)                                                                 \
-  {                                                                                                  \
-    if (wide && p.late_grid < 0) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 0>), dim3((unsigned)tiles), block, 0, s, p);        \
-    else if (wide && late) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 2>), grid, block, 0, s, p);   \
-    else if (wide) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, true, 1>), grid, block, 0, s, p);      \
-    else hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, false, 0>), grid, block, 0, s, p);               \
+#define HC_HYST_LAUNCH_P(TR_, WAVES_, PANELS_)                                                             \
+  {                                                                                                         \
+    if (!lists) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, PANELS_, 0>), grid, block, 0, s, p);             \
+    else if (late) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, PANELS_, 2>), grid, block, 0, s, p);          \
+    else hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, PANELS_, 1>), grid, block, 0, s, p);                    \
+  }
+#define HC_HYST_LAUNCH(TR_, WAVES_)                 \
+  {                                                  \
+    if (wide) HC_HYST_LAUNCH_P(TR_, WAVES_, true)    \
+    else HC_HYST_LAUNCH_P(TR_, WAVES_, false)        \
   }
   if (g.nw == 1 && g.tr == 32 && g.waves == 8) HC_HYST_LAUNCH(32, 8)
   else if (g.nw == 1 && g.tr == 32 && g.waves == 4) HC_HYST_LAUNCH(32, 4)
@@ -2046,6 +2050,7 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   else if (g.nw == 1 && g.tr == 16 && g.waves == 2) HC_HYST_LAUNCH(16, 2)
 
 #undef HC_HYST_LAUNCH
+#undef HC_HYST_LAUNCH_P
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

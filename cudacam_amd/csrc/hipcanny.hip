@@ -78,6 +78,7 @@ struct hc_ctx {
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
   u32 wl_prev[MAX_HYST_LAUNCHES + 1] = { 0 };  // worklist lengths of the last finished run's launches
   size_t wl_prev_tiles = 0;                    // ... and its tile count (0: none / not a wide-frame run)
+  bool hyst_lists_last = false;        // the last run used the worklist scheme
   int hyst_late_grid = 0;              // diagnostics (HC_HYST_LATE_GRID): workgroups of the hysteresis launches >= 1
   int hyst_rows_last = 0;              // rows per wave of the last run's hysteresis tiles
   int hyst_waves_last = 0;             // waves per hysteresis workgroup of the last run (adaptive tile height, queue_hyst_expand)
@@ -258,7 +259,7 @@ int finish_slot(hc_ctx *c, Slot &s)
   c->last_work_launches = std::min(K, work + 1);
   c->last_continued = 0;
   // worklist lengths of this run's launches (wide frames): the next run of the same shape sizes its grids by them
-  c->wl_prev_tiles = s.ph.npanels > 1 ? s.ph.wl_stride : 0;
+  c->wl_prev_tiles = (s.ph.npanels > 1 || s.ph.lists) ? s.ph.wl_stride : 0;
   for (int k = 0; k <= MAX_HYST_LAUNCHES; ++k) c->wl_prev[k] = s.h_flags[FLAG_WORDS + k];
   const int tile = s.ph.tile_rows * s.ph.waves;
   c->hyst_need_rows = std::max(c->last_work_launches * tile, c->hyst_need_rows - 32);  // follows the content up at once, down slowly
@@ -267,6 +268,7 @@ int finish_slot(hc_ctx *c, Slot &s)
   for (int round = 0; round < 1000000; ++round) {
     HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * s.ph.wl_stride), st));  // flags, worklist counts and reasons
     HystParams hp = s.ph;
+    hp.late_grid = c->hyst_late_grid > 0 ? c->hyst_late_grid : 0;  // (not the grid of the run's last queued launch)
     hp.first_pass = 0;
     hp.stats = nullptr;
     for (int k = 0; k < K; ++k) {
@@ -338,19 +340,25 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   hp.wl_reason = s.d_flags + FLAG_WORDS + WL_COUNT_WORDS;
   hp.wl_list = s.d_wl_list;
   HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * hp.wl_stride), st));
+  // Worklists or a workgroup per tile in every launch (k_hyst)?  Lists where the step follows the hysteresis chain:
+  // frames wider than one panel -- unless they are dense (the last run visited more than 60 % of the tiles in launch 1:
+  // noise; camera-like frames: a third; the front kernel, which bounds such streams, loses less to a hysteresis that is
+  // spread over it: 33.6 against 30.8 k frames/s on 4K noise) -- and one-panel streams whose runs need 20 launches or more
+  // (BGR frames blended into grey: 25 launches, 205 -> 222 k frames/s; the 16 launches of 1080p grey frames fit inside
+  // the front kernel's time, and there the lists cost 2 %).
+  if (c->hyst_late_grid) hp.lists = c->hyst_late_grid > 0;
+  else if (hp.npanels > 1) hp.lists = !(c->wl_prev_tiles == hp.wl_stride && (size_t)c->wl_prev[1] * 5 > hp.wl_stride * 3);
+  else hp.lists = c->last_work_launches >= 20 || (c->hyst_lists_last && c->last_work_launches >= 14);
+  c->hyst_lists_last = hp.lists != 0;
   hp.first_pass = 1;
   hp.prov = s.prov ? 1 : 0;
   for (int k = 0; k < K; ++k) {
     hp.iter = k;
-    // wide frames, launches >= 1: a workgroup per worklist entry.  Grid: twice what the last run of this shape listed for
+    // worklist scheme, launches >= 1: a workgroup per list entry.  Grid: twice what the last run of this shape listed for
     // the launch (entries beyond the grid wait a launch: a dense frame would need several launches more); without such
     // a run, launch_hyst's schedule by the tile count
-    hp.late_grid = c->hyst_late_grid;
-    // ... unless the frames are dense (the last run visited more than 60 % of the tiles in launch 1 -- noise; camera-like frames: a third): then the
-    // launches stay a workgroup per tile (late_grid -1: MODE 0 of k_hyst; the front kernel, which bounds such streams,
-    // loses less to a hysteresis that is spread over it: 33.6 against 30.8 k frames/s on 4K noise)
-    if (!hp.late_grid && c->wl_prev_tiles == hp.wl_stride && hp.npanels > 1 && (size_t)c->wl_prev[1] * 5 > hp.wl_stride * 3) hp.late_grid = -1;
-    if (!hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>(2048, 2 * (size_t)c->wl_prev[k] + 256));
+    hp.late_grid = c->hyst_late_grid > 0 ? c->hyst_late_grid : 0;
+    if (hp.lists && !hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>(2048, 2 * (size_t)c->wl_prev[k] + 256));
     // diagnostics cost ~3 same-address atomics per wave (hundreds of microseconds per launch): opt-in only
     hp.stats = c->hyst_diag ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
     HIPCK(launch_hyst(hp, st));

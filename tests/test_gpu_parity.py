@@ -393,27 +393,30 @@ def test_pipelined_runs(oracle, w, h, mode):
         _diff(d_out[0].cpu().numpy()[1, :, :w], want[0][1], "plain mode after pipelined mode")
 
 
+@pytest.mark.parametrize("w", [4500, 900])
 @pytest.mark.parametrize("grid", ["1", "3"])
-def test_wide_frame_worklists_with_tiny_grids(oracle, grid, monkeypatch):
-    """Frames wider than one 2048-column panel: launches >= 1 of the hysteresis take their tiles from worklists, one entry
-    per workgroup; entries beyond the grid are handed on to the next launch.  HC_HYST_LATE_GRID (read by hc_create) forces
-    grids of 1 and 3 workgroups, so nearly every entry of every launch takes that road -- serpentine chains that cross
-    panel seams and row tiles, plain and pipelined, must still reach the exact fixpoint (through the host-side
-    continuation when the queued launches run out)."""
+def test_hysteresis_worklists_with_tiny_grids(oracle, grid, w, monkeypatch):
+    """The worklist form of the hysteresis (frames wider than one 2048-column panel; one-panel streams that need 20
+    launches or more): launches >= 1 take their tiles from lists, one entry per workgroup; entries beyond the grid are
+    handed on to the next launch.  HC_HYST_LATE_GRID (read by hc_create) forces the lists and grids of 1 and 3
+    workgroups, so nearly every entry of every launch takes that road -- serpentine chains that cross panel seams and
+    row tiles, plain and pipelined, must still reach the exact fixpoint (through the host-side continuation when the
+    queued launches run out)."""
     import torch
     monkeypatch.setenv("HC_HYST_LATE_GRID", grid)
-    w, h, nb = 4500, 200, 2
+    h, nb = 200, 2
     frames = np.stack([synth.serpentine(w, h, amp=20, seed_amp=120), synth.natural(w, h, 77)])
     want = oracle.canny_r_batch(frames, 10, 40, threads=4)
     with api.Context(w, h, 1, nb) as ctx:
         got = ctx.process(frames)
         for f in range(nb):
             _diff(got[f], want[f], f"tiny late grid {grid}, frame {f}")
-        d_in = torch.from_numpy(np.ascontiguousarray(np.pad(frames, ((0, 0), (0, 0), (0, 4504 - w))))).cuda()
+        pitch = (w + 7) // 8 * 8
+        d_in = torch.from_numpy(np.ascontiguousarray(np.pad(frames, ((0, 0), (0, 0), (0, pitch - w))))).cuda()
         d_out = [torch.zeros_like(d_in) for _ in range(2)]
         ctx.set_option(api.OPT_PIPELINE, 1)
         for r in range(4):
-            ctx.run_device(d_in.data_ptr(), 4504, 4504 * h, d_out[r % 2].data_ptr(), 4504, 4504 * h, nb)
+            ctx.run_device(d_in.data_ptr(), pitch, pitch * h, d_out[r % 2].data_ptr(), pitch, pitch * h, nb)
         ctx.sync()
         for o in d_out:
             for f in range(nb):
