@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_front8o(const FrontParams p)
     const bool valid = (u32)(c - r0) < (u32)(rend - r0);
     bool q0, q1;  // the half-lane may hold (L2) / holds (L1) a pixel with m > low
     if constexpr (L2) {
-      q0 = max(T2[0], T2[1]) >= nec; q1 = max(T2[2], T2[3]) >= nec;
+      q0 = __builtin_elementwise_max(T2[0], T2[1]) >= nec; q1 = __builtin_elementwise_max(T2[2], T2[3]) >= nec;
     } else {
       // any of the four 16-bit magnitudes > low  <=>  bit 15 of (m + 0x7FFF - low) in one of the halves (low <= 32767)
       const u32 g0 = R(__builtin_elementwise_max(U(T2[0]), U(T2[1]))), g1 = R(__builtin_elementwise_max(U(T2[2]), U(T2[3])));
