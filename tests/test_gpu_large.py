@@ -60,3 +60,21 @@ def test_4k_batch_matches_oracle(oracle):
         got = ctx.process(frames)
     for f in range(3):
         _diff(got[f], want[f], f"4K frame {f}")
+
+
+@pytest.mark.parametrize("l2", [0, 1])
+def test_8k_mode_o_matches_restatement(oracle, l2):
+    """cv::Canny semantics at full size: k_front8o (8 px per lane, id-only queue, replicate border in the batch) on an
+    8K frame and on BASELINE configs[1]'s 1920x1080, bit planes before the flood and final map, both gradient norms."""
+    for img, tag in ((_plane(9, "natural"), "8K"), (synth.natural(1920, 1080, 17), "1080p")):
+        low, high = (50, 150) if not l2 else (40, 120)
+        edges, pre = oracle.canny_o_stages(img, low, high, bool(l2))
+        h, w = img.shape
+        with api.Context(w, h, 1, 1, mode=api.MODE_O) as ctx:
+            ctx.set_thresholds(low, high)
+            ctx.set_option(api.OPT_L2_GRADIENT, l2)
+            ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+            got = ctx.process(img)[0]
+            assert ctx.last_run_info()[2] == 3
+            _diff(ctx.debug_tap(api.TAP_THRESH)[0], pre, f"{tag} mode O l2={l2}: bit planes of k_front8o")
+            _diff(got, edges, f"{tag} mode O l2={l2}: edges")
