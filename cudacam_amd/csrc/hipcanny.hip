@@ -55,6 +55,7 @@ struct Slot {
   int k_launches = 0;            // hysteresis launches queued for this run
   bool prov = false;             // this run's k_nms wrote the provisional output
   hipStream_t stream = nullptr;  // stream the hysteresis of this run was queued on
+  int hyst_level = 0;            // tile height level of this run's hysteresis (hc_ctx::hyst_obs index)
   uintptr_t out0 = 0, out1 = 0;  // output range of this (pipelined, still pending) run: a later run into the same memory waits for it
 };
 }  // namespace
@@ -80,9 +81,8 @@ struct hc_ctx {
   size_t wl_prev_tiles = 0;                    // ... and its tile count (0: none / not a wide-frame run)
   bool hyst_lists_last = false;        // the last run used the worklist scheme
   int hyst_late_grid = 0;              // diagnostics (HC_HYST_LATE_GRID): workgroups of the hysteresis launches >= 1
-  int hyst_rows_last = 0;              // rows per wave of the last run's hysteresis tiles
-  int hyst_waves_last = 0;             // waves per hysteresis workgroup of the last run (adaptive tile height, queue_hyst_expand)
-  bool hyst_waves_last_small = false;  // ... and whether that run was a pipelined one (different base shape)
+  int hyst_obs[3] = { 0, 0, 0 };       // hysteresis launches the last runs needed with base_waves << i waves per workgroup (0: not seen)
+  int hyst_obs_base = 0, hyst_obs_rows = 0;  // the base shape those observations belong to
   int split = 2;        // Mode R front path: 2 = k_front8 (one kernel, 8 px per lane; default), 1 = k_blur + k_nms, 0 = the 4-px fused k_front
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
   uint8_t *d_dump = nullptr;    // k_front8's dump area (FrontParams::dump), followed by its page of zeros (FrontParams::zeros)
@@ -263,7 +263,19 @@ int finish_slot(hc_ctx *c, Slot &s)
   for (int k = 0; k <= MAX_HYST_LAUNCHES; ++k) c->wl_prev[k] = s.h_flags[FLAG_WORDS + k];
   const int tile = s.ph.tile_rows * s.ph.waves;
   c->hyst_need_rows = std::max(c->last_work_launches * tile, c->hyst_need_rows - 32);  // follows the content up at once, down slowly
-  if (s.h_flags[K - 1] == 0) return HC_OK;
+  // launches this run needed at its tile height (queue_hyst_expand picks the next runs' height from these)
+  auto observe = [&]() {
+    const int lvl = s.hyst_level, L = c->last_work_launches;
+    if ((s.ph.waves >> lvl) != c->hyst_obs_base || s.ph.tile_rows != c->hyst_obs_rows) return;
+    const int o = c->hyst_obs[lvl];
+    // the content changed: what was seen at the other heights no longer holds
+    if (o && (L * 10 > o * 13 + 20 || L * 10 < o * 7 - 20)) c->hyst_obs[0] = c->hyst_obs[1] = c->hyst_obs[2] = 0;
+    c->hyst_obs[lvl] = L;
+  };
+  if (s.h_flags[K - 1] == 0) {
+    observe();
+    return HC_OK;
+  }
   c->last_continued = 1;
   for (int round = 0; round < 1000000; ++round) {
     HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * s.ph.wl_stride), st));  // flags, worklist counts and reasons
@@ -281,6 +293,7 @@ int finish_slot(hc_ctx *c, Slot &s)
     if (s.h_flags[K - 1] == 0) break;
   }
   c->hyst_need_rows = std::max(c->hyst_need_rows, c->last_work_launches * tile);
+  observe();
   if (s.copy_dst)
     if (int rc = copy_frames_d2d(c, st, s.copy_dst, s.copy_pitch, s.copy_fs, s.ph.out, s.ph.out_pitch, s.ph.out_frame_stride, (size_t)c->W, s.n)) return rc;
   HIPCK(hipStreamSynchronize(st));
@@ -302,19 +315,34 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags;
   // one workgroup per (frame, tile of waves x tile_rows rows); the geometry follows the row width
   hyst_tile_geometry(c->hyst_geom, small_tiles, (long)n * c->H, c->H, &hp.tile_rows, &hp.waves);
-  // Adaptive: a launch carries a change across one tile boundary, so frames whose weak edges wind through many tiles need
-  // many launches (three natural images blended into one grey frame: 56 with 64-row tiles).  The next runs use tiles
-  // tall enough for about 20 launches, and queue as many launches as the last ones needed, + 2 -- a stream of similar
-  // frames stops needing the host-side continuation (which stalls the pipeline) after its first step.
-  while (hp.waves < 8 && c->hyst_need_rows > 20 * hp.tile_rows * hp.waves) hp.waves *= 2;
-  // ... and stay with them while the runs still need more than 4 launches there: the launch count at tall tiles says
-  // little about the count at shorter ones (Mode O frames: 6 launches at 128 rows, 22 at 64 -- coming back down by the
-  // row estimate alone made the shape flip every few runs, each flip a host-side continuation that stalls the pipeline
-  // for a millisecond)
-  if (c->hyst_waves_last > hp.waves && small_tiles == c->hyst_waves_last_small && hp.tile_rows == c->hyst_rows_last && c->hyst_need_rows > 4 * hp.tile_rows * c->hyst_waves_last) hp.waves = c->hyst_waves_last;
-  c->hyst_waves_last = hp.waves;
-  c->hyst_waves_last_small = small_tiles;
-  c->hyst_rows_last = hp.tile_rows;
+  // Adaptive tile height: a launch carries a change across one tile boundary, so frames whose weak edges wind through
+  // many tiles need many launches.  The library remembers how many launches the runs needed with the base shape and
+  // with twice / four times its waves (hyst_obs, updated by finish_slot, forgotten when the content changes): above 20
+  // launches the next taller shape is tried -- and kept only if it needs fewer than 60 % of the launches.  Mode O frames:
+  // 24 launches with 64-row tiles, 5 with 128 rows: taller (501 against 480 k frames/s).  BGR frames blended into grey:
+  // 25 either way, their chains wind around the tile boundaries whatever the height: the small workgroups, which find
+  // room beside the front kernel more easily, and the worklists (255 against 224 k frames/s with 4-wave tiles).
+  // (Round 2's first rule went by rows -- launches x tile height -- alone: it kept the BGR stream on tall tiles, and
+  // made the Mode O stream flip between the two shapes every few runs, each flip a host-side continuation.)
+  const int base_waves = hp.waves;
+  if (base_waves != c->hyst_obs_base || hp.tile_rows != c->hyst_obs_rows) {  // another base shape (batch size, plain / pipelined): start over
+    c->hyst_obs_base = base_waves; c->hyst_obs_rows = hp.tile_rows;
+    c->hyst_obs[0] = c->hyst_obs[1] = c->hyst_obs[2] = 0;
+  }
+  int lvl = 0;
+  while (lvl < 2 && (base_waves << (lvl + 1)) <= 8) {
+    const int cur = c->hyst_obs[lvl], nxt = c->hyst_obs[lvl + 1];
+    if (cur <= 20) break;                  // unknown (0) or few enough
+    if (nxt != 0 && nxt * 5 > cur * 3) {  // the taller tiles did not pay
+      // (frames of several panels: the tallest then -- an 8K grey stream whose weak edge wobbles along a tile boundary
+      // needs 53 launches at every height, and runs them faster on a quarter of the tiles: 21.1 against 16.5 k frames/s)
+      if (c->RD > 64) while (lvl < 2 && (base_waves << (lvl + 1)) <= 8) ++lvl;
+      break;
+    }
+    ++lvl;
+  }
+  hp.waves = base_waves << lvl;
+  s.hyst_level = lvl;
   hp.nrtiles = (c->H + hp.tile_rows * hp.waves - 1) / (hp.tile_rows * hp.waves);
   hp.npanels = (c->RD + 63) / 64;
   // launches queued per run: the user's number, or by default enough for an edge that crosses every row tile of a
