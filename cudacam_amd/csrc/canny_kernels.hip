@@ -1824,8 +1824,13 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
       for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
       uint8_t *dst = obase + (size_t)row * p.out_pitch + c0;
       if (c0 + 15 < p.W) {
-        if (a16) *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
-        else
+        if (a16) {
+          // (the pointer goes through an empty asm: seeing two branches that store the same bytes, the optimizer otherwise
+          //  merges them into the four dword stores -- twice the store instructions of the full-map launch)
+          uint8_t *d16 = dst;
+          asm volatile("" : "+v"(d16));
+          *reinterpret_cast<uint4 *>(d16) = make_uint4(v[0], v[1], v[2], v[3]);
+        } else
 #pragma unroll
           for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
       } else {
@@ -1853,20 +1858,31 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
           const u32 x = __shfl(rowv, 32 * pass + (lane >> 1));  // before any lane drops out: the permute only sees active lanes
           const u32 b = (x >> (16 * (lane & 1))) & 0xFFFFu;
           const int c0 = pcol * 32 + pass * 1024 + lane * 16;
-          if (c0 >= p.W) continue;
+          if (c0 + 15 >= p.W) continue;  // whole 16-pixel groups here; the ragged last group of a row below
           u32 v[4];
 #pragma unroll
           for (int k = 0; k < 4; ++k) v[k] = nibble_to_bytes((b >> (4 * k)) & 0xFu);
           uint8_t *dst = orow + c0;
-          if (c0 + 15 < p.W) {
-            if (a16) *reinterpret_cast<uint4 *>(dst) = make_uint4(v[0], v[1], v[2], v[3]);
-            else
+          if (a16) {
+            uint8_t *d16 = dst;
+            asm volatile("" : "+v"(d16));  // (keeps the 16-byte store: see put16)
+            *reinterpret_cast<uint4 *>(d16) = make_uint4(v[0], v[1], v[2], v[3]);
+          } else
 #pragma unroll
-              for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
-          } else {
-#pragma nounroll  // (unrolled, the 16 exec masks of this ragged last group cost the kernel an SGPR spill, i.e. a VGPR: 81 instead of 80)
-            for (int k = 0; k < 16 && c0 + k < p.W; ++k) dst[k] = ((b >> k) & 1u) ? (uint8_t)255 : (uint8_t)0;
-          }
+            for (int k = 0; k < 4; ++k) reinterpret_cast<u32 *>(dst)[k] = v[k];
+        }
+      }
+      // Widths that are not a multiple of 16: the last W % 16 pixels of every row, a byte per lane, in a loop of their own
+      // (inside the loop above, the byte-wise tail -- unrolled 16 times under 16 exec masks -- cost the kernel an SGPR
+      // spill, i.e. an 81st VGPR, and as a plain loop it made the compiler split the hot loop: 0.94 instead of 0.76 ms
+      // for launch 0 of 1024 frames in plain mode)
+      const int ragged = p.W & 15, cl = p.W - ragged;  // first column of the ragged group
+      if (ragged != 0 && cl >= pcol * 32 && cl < (pcol + ROWW) * 32) {
+        const int hw = (cl - pcol * 32) >> 4;  // its half-word in the panel row: dword hw / 2 is held by lane hw / 2
+        for (int r = 0; r < n; ++r) {
+          const u32 x = __shfl(sr[0][r], hw >> 1);
+          const u32 b = (x >> (16 * (hw & 1))) & 0xFFFFu;
+          if (lane < ragged) (obase + (size_t)(b0 + w0 + r) * p.out_pitch + cl)[lane] = ((b >> lane) & 1u) ? (uint8_t)255 : (uint8_t)0;
         }
       }
     } else {
