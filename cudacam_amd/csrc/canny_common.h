@@ -102,6 +102,8 @@ hipError_t launch_blur(const FrontParams &p, hipStream_t s);
 hipError_t launch_nms(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
+// pitched device-to-device copy of n frames (any alignment on either side); rows, n <= 65535
+hipError_t launch_copy_rows(void *dst, size_t dpitch, size_t dfs, const void *src, size_t spitch, size_t sfs, size_t row_bytes, int rows, int n, hipStream_t s);
 size_t front_lds_bytes();
 int front_run_rows(int subchunks);
 void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, int *tile_rows, int *waves);

@@ -1382,6 +1382,35 @@ __global__ __launch_bounds__(256) void k_pack(const PackParams p)
   }
 }
 
+// =================================================================================================
+// k_copy_rows: pitched device-to-device copy of n frames of `rows` rows of `row_bytes` bytes -- how caller buffers that the
+// kernels cannot use in place (pointer / pitch / frame stride not a multiple of 4, rows that do not hold whole pixel
+// groups) reach the context's internal pitched buffers and back.  16 bytes per lane, any alignment on either side (the
+// hardware takes unaligned global dwordx4 accesses); the row-by-row DMA of hipMemcpy2DAsync moved 512 frames of
+// 1918 x 1079 in 1.5 - 2.5 ms each way.
+// =================================================================================================
+typedef u32 u32x4_any __attribute__((ext_vector_type(4), aligned(1)));
+__global__ __launch_bounds__(256) void k_copy_rows(uint8_t *dst, size_t dpitch, size_t dfs, const uint8_t *src, size_t spitch, size_t sfs, unsigned row_bytes, int rows)
+{
+  const unsigned x = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  const int row = blockIdx.y, f = blockIdx.z;
+  if (x >= row_bytes || row >= rows) return;
+  const uint8_t *q = src + (size_t)f * sfs + (size_t)row * spitch + x;
+  uint8_t *d = dst + (size_t)f * dfs + (size_t)row * dpitch + x;
+  if (x + 16u <= row_bytes) *reinterpret_cast<u32x4_any *>(d) = *reinterpret_cast<const u32x4_any *>(q);
+  else
+    for (unsigned k = 0; x + k < row_bytes; ++k) d[k] = q[k];
+}
+
+hipError_t launch_copy_rows(void *dst, size_t dpitch, size_t dfs, const void *src, size_t spitch, size_t sfs, size_t row_bytes, int rows, int n, hipStream_t s)
+{
+  if (row_bytes == 0 || rows <= 0 || n <= 0) return hipSuccess;
+  if (row_bytes > 0x7FFFFFFFull || rows > 65535 || n > 65535) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)((row_bytes + 4095) / 4096), (unsigned)rows, (unsigned)n), block(256);
+  hipLaunchKernelGGL(k_copy_rows, grid, block, 0, s, (uint8_t *)dst, dpitch, dfs, (const uint8_t *)src, spitch, sfs, (unsigned)row_bytes, rows);
+  return hipGetLastError();
+}
+
 hipError_t launch_pack(const PackParams &p, hipStream_t s)
 {
   const long long total = (long long)p.nframes * p.H * ((p.W + 255) / 256);

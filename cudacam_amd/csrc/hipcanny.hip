@@ -233,11 +233,10 @@ void band_thresholds(int T, bool saturate, u32 a[3])
 
 int copy_frames_d2d(hc_ctx *c, hipStream_t st, void *dst, size_t dpitch, size_t dfs, const void *src, size_t spitch, size_t sfs, size_t row_bytes, int n)
 {
-  if (dfs == dpitch * (size_t)c->H && sfs == spitch * (size_t)c->H) {
-    HIPCK(hipMemcpy2DAsync(dst, dpitch, src, spitch, row_bytes, (size_t)c->H * n, hipMemcpyDeviceToDevice, st));
-  } else {
-    for (int f = 0; f < n; ++f)
-      HIPCK(hipMemcpy2DAsync((uint8_t *)dst + dfs * f, dpitch, (const uint8_t *)src + sfs * f, spitch, row_bytes, (size_t)c->H, hipMemcpyDeviceToDevice, st));
+  // a kernel, not hipMemcpy2DAsync: its row-by-row DMA took 1.5 - 2.5 ms for 512 frames of 1918 x 1079 (k_copy_rows: 0.3 ms)
+  for (int f0 = 0; f0 < n; f0 += 65535) {
+    const int nf = std::min(n - f0, 65535);
+    HIPCK(launch_copy_rows((uint8_t *)dst + dfs * f0, dpitch, dfs, (const uint8_t *)src + sfs * f0, spitch, sfs, row_bytes, c->H, nf, st));
   }
   return HC_OK;
 }
