@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--hyst-launches", type=int, default=0, help="hysteresis launches queued per run (0 = auto)")
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
-    ap.add_argument("--out-buffers", type=int, default=2, help="pipelined mode: output buffers used in turn (a run into memory that an earlier, still unfinished run writes waits for that run)")
+    ap.add_argument("--out-buffers", type=int, default=0, help="pipelined mode: output buffers used in turn (a run into memory that an earlier, still unfinished run writes waits for that run); 0 = as many as the context keeps runs in flight: 2, or 4 for small batches")
     ap.add_argument("--front", default="front8", choices=["front8", "split", "fused4"], help="front path (HC_OPT_FRONT_SPLIT): front8 = one kernel, 8 px per lane (default; Mode O: k_front8o); split = k_blur + k_nms; fused4 = the 4-px fused kernel (Mode O: both = k_front_o)")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3], help="3: interleaved BGR input (grey conversion fused into the load)")
@@ -118,7 +118,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     n_out = 3 * B if a.per_channel else B
     # two output batches used in turn, as a pipelined consumer would (run i's maps are read while run i+1 computes);
     # with a single one the library falls back to the non-provisional expand to keep run i+1's map intact
-    d_outs = [torch.empty((n_out, H, W), dtype=torch.uint8, device=dev) for _ in range(1 if a.no_pipeline else a.out_buffers)]
+    d_outs = [torch.empty((n_out, H, W), dtype=torch.uint8, device=dev) for _ in range(1 if a.no_pipeline else (a.out_buffers or (4 if n_out * H < 256 * 1024 else 2)))]
     d_out = d_outs[0]
     del d_u
 

@@ -36,11 +36,13 @@ constexpr int WL_COUNT_WORDS = 128;
 static_assert(WL_COUNT_WORDS >= MAX_HYST_LAUNCHES + 1, "a count per launch and one beyond the last");
 
 // Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's hysteresis (pipelined
-// mode); the plain mode only uses slot 0.  (Three were measured: run i+1 then no longer waits for the hysteresis of run
-// i-1 -- no difference at 1080p in either mode, at 4K, with BGR input or at 8K x 3: where the step is longer than the front
-// kernel, it is the hysteresis stream that is full -- its launch 0 runs starved beside the front kernel for as long as
-// that takes, the later launches follow -- and a third slot only lets it fall further behind.)
-constexpr int NSLOT = 2;
+// mode); the plain mode only uses slot 0.  (Three were measured on big batches: run i+1 then no longer waits for the
+// hysteresis of run i-1 -- no difference at 1080p in either mode, at 4K, with BGR input or at 8K x 3: where the step is
+// longer than the front kernel, it is the hysteresis stream that is full, and a third slot only lets it fall further
+// behind.)  SMALL batches use four slots, each with a hysteresis stream of its own: there a step is the latency of the
+// hysteresis' chain of dependent launches (8 frames: 0.33 ms for a 0.04 ms front kernel), and chains of different runs
+// share the device without noticing each other.
+constexpr int NSLOT = 4;
 struct Slot {
   u32 *d_sbits = nullptr, *d_cbits = nullptr;  // bit planes [max_batch][H][RD]
   u32 *d_wl_list = nullptr;  // hysteresis worklists (HystParams::wl_list)
@@ -55,6 +57,7 @@ struct Slot {
   int k_launches = 0;            // hysteresis launches queued for this run
   bool prov = false;             // this run's k_nms wrote the provisional output
   hipStream_t stream = nullptr;  // stream the hysteresis of this run was queued on
+  hipStream_t s_hyst = nullptr;  // this slot's hysteresis stream (pipelined mode)
   int hyst_level = 0;            // tile height level of this run's hysteresis (hc_ctx::hyst_obs index)
   uintptr_t out0 = 0, out1 = 0;  // output range of this (pipelined, still pending) run: a later run into the same memory waits for it
 };
@@ -65,7 +68,6 @@ struct hc_ctx {
   int low = 10, high = 40;
   int nms_saturate = 0;
   hipStream_t own_stream = nullptr, stream = nullptr;  // context stream (own, or the caller's)
-  hipStream_t s_hyst = nullptr;                        // pipelined mode: hysteresis + expand (the front kernels stay on `stream`)
   // internal pitched frames
   uint8_t *d_in = nullptr, *d_mono = nullptr, *d_out = nullptr;
   size_t in_pitch = 0, in_fs = 0, mono_pitch = 0, mono_fs = 0, out_pitch = 0, out_fs = 0;
@@ -74,6 +76,7 @@ struct hc_ctx {
   int16_t *d_sx = nullptr, *d_sy = nullptr;
   // fused path
   Slot slot[NSLOT];
+  int nslot_use = 2;  // slots the pipelined runs rotate through (4 for small batches)
   int cur = 0;
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
@@ -162,6 +165,13 @@ int alloc_slot(hc_ctx *c, Slot &s)
   HIPCK(hipMalloc((void **)&s.d_wl_list, sizeof(u32) * 2 * s.wl_cap));
   HIPCK(hipMalloc((void **)&s.d_flags, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * s.wl_cap)));
   HIPCK(hipHostMalloc((void **)&s.h_flags, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS), hipHostMallocDefault));
+  {
+    // the hysteresis launches are few, small and dependent (latency-bound); at the highest priority their workgroups are
+    // placed ahead of the next run's 30k-wave front kernel instead of behind it
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    HIPCK(hipStreamCreateWithPriority(&s.s_hyst, hipStreamNonBlocking, greatest));
+  }
   HIPCK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
   HIPCK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
   return HC_OK;
@@ -173,6 +183,7 @@ void free_slot(Slot &s)
   if (s.h_flags) (void)hipHostFree(s.h_flags);
   if (s.ev_front) (void)hipEventDestroy(s.ev_front);
   if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+  if (s.s_hyst) (void)hipStreamDestroy(s.s_hyst);
   s = Slot{};
 }
 
@@ -302,8 +313,10 @@ int finish_slot(hc_ctx *c, Slot &s)
 int finish_all(hc_ctx *c)
 {
   // oldest first: slot `cur` is the next to be reused
-  for (int k = 0; k < NSLOT; ++k)
-    if (int rc = finish_slot(c, c->slot[(c->cur + k) % NSLOT])) return rc;
+  for (int k = 0; k < c->nslot_use; ++k)
+    if (int rc = finish_slot(c, c->slot[(c->cur + k) % c->nslot_use])) return rc;
+  for (Slot &q : c->slot)  // (slots of the other ring size hold nothing: the ring is drained before its size changes)
+    if (int rc = finish_slot(c, q)) return rc;
   return HC_OK;
 }
 
@@ -409,6 +422,16 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   const int W = c->W, H = c->H;
   const int n_out = c->per_channel ? 3 * n : n;  // output frames (= bit-plane frames)
   const bool piped = c->pipeline && stage == HC_STAGE_HYSTER;
+  if (piped) {
+    // big batches rotate through two slots, small ones (the step is the latency of the hysteresis chain) through four
+    // (measured at 1080p: 128 frames per run 237 against 218 k frames/s with four, 256 frames 301 against 310 k)
+    const int use = (long)n_out * H < 256 * 1024 ? NSLOT : 2;
+    if (use != c->nslot_use) {
+      if (int rc = finish_all(c)) return rc;
+      c->nslot_use = use;
+      c->cur = 0;
+    }
+  }
   Slot &s = c->slot[piped ? c->cur : 0];
   if (piped) {
     if (int rc = alloc_slot(c, s)) return rc;
@@ -418,7 +441,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   // it did to the input before this call, whatever it does to it afterwards); pipelined mode puts the rest on s_hyst.
   // (A separate front stream tied to the context stream by events cost a 50 us bubble per run: every cross-stream wait
   // is a round trip through the command processor.)
-  hipStream_t sf = c->stream, sh = piped ? c->s_hyst : c->stream;
+  hipStream_t sf = c->stream, sh = piped ? s.s_hyst : c->stream;
   // unaligned caller buffers go through the internal pitched ones
   const uint8_t *src = in;
   size_t sp = in_pitch, sfs = in_fs;
@@ -509,10 +532,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       // continuation rewrites whole maps (finish_slot) and would otherwise land on top of this run's result.  The same
       // for an older run still in flight (a caller that alternates two output buffers): it is waited for, oldest first
       // (once complete it patches nothing any more, so the shortcut stays).
-      for (int k = 1; k < NSLOT; ++k) {
-        Slot &o = c->slot[(c->cur + k) % NSLOT];  // k = NSLOT - 1: the previous run
+      for (int k = 1; k < c->nslot_use; ++k) {
+        Slot &o = c->slot[(c->cur + k) % c->nslot_use];  // k = nslot_use - 1: the previous run
         if (!(o.out0 < o1 && o0 < o.out1)) continue;
-        if (k == NSLOT - 1) out_overlap = true;
+        if (k == c->nslot_use - 1) out_overlap = true;
         if (int rc = finish_slot(c, o)) return rc;
       }
     }
@@ -644,7 +667,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     c->ev_count++;
   }
   if (stage == HC_STAGE_HYSTER) HIPCK(hipEventRecord(s.ev_done, sh));
-  if (piped) c->cur = (c->cur + 1) % NSLOT;
+  if (piped) c->cur = (c->cur + 1) % c->nslot_use;
   c->last_run_n = n_out;
   return HC_OK;
 }
@@ -699,13 +722,6 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
     return false;
   };
   bool good = ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
-  {
-    // pipelined mode: the hysteresis launches are few, small and dependent (latency-bound); at the highest
-    // priority their workgroups are placed ahead of the next run's 30k-wave front kernel instead of behind it
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    good = good && ok(hipStreamCreateWithPriority(&c->s_hyst, hipStreamNonBlocking, greatest), "hipStreamCreateWithPriority");
-  }
   c->stream = c->own_stream;
   c->hyst_diag = getenv("HC_HYST_DIAG") != nullptr;
   if (const char *e = getenv("HC_HYST_LATE_GRID")) c->hyst_late_grid = std::max(-1, atoi(e));  // tests: tiny grids exercise the hand-on of worklist entries
@@ -743,7 +759,7 @@ void hc_destroy(hc_ctx *c)
   for (Slot &q : c->slot) free_slot(q);
   free_debug_buffers(c);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
-  for (hipStream_t st : { c->own_stream, c->s_hyst }) if (st) (void)hipStreamDestroy(st);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -824,11 +840,10 @@ int hc_set_option(hc_ctx *c, int option, int value)
     c->dbg_frames = 0;
   } else if (option == HC_OPT_PIPELINE) {
     HIPCK(hipSetDevice(c->device));
-    if (value)
-      for (int k = 1; k < NSLOT; ++k)
-        if (alloc_slot(c, c->slot[k]) != HC_OK) return HC_E_HIP;
+    if (value && alloc_slot(c, c->slot[1]) != HC_OK) return HC_E_HIP;  // (the slots of the four-slot ring are allocated by the small batches that use them)
     c->pipeline = value != 0;
     c->cur = 0;
+    c->nslot_use = 2;
   } else return fail(HC_E_ARG, "hc_set_option: unknown option");
   return HC_OK;
 }
@@ -898,7 +913,8 @@ int hc_sync(hc_ctx *c)
   if (!c) return fail(HC_E_ARG, "null context");
   HIPCK(hipSetDevice(c->device));
   if (int rc = finish_all(c)) return rc;
-  HIPCK(hipStreamSynchronize(c->s_hyst));
+  for (Slot &q : c->slot)
+    if (q.s_hyst) HIPCK(hipStreamSynchronize(q.s_hyst));
   HIPCK(hipStreamSynchronize(c->stream));
   while (c->ev_count > 0) {  // collect the event intervals of every run recorded since the last sync
     hipEvent_t *e = &c->evpool[(size_t)c->ev_head * hc_ctx::EV_PER_RUN];

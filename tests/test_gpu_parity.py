@@ -423,6 +423,37 @@ def test_hysteresis_worklists_with_tiny_grids(oracle, grid, w, monkeypatch):
                 _diff(o.cpu().numpy()[f, :, :w], want[f], f"tiny late grid {grid}, pipelined, frame {f}")
 
 
+@pytest.mark.parametrize("nbuf", [1, 2, 3, 4, 5])
+def test_small_batches_keep_four_runs_in_flight(oracle, nbuf):
+    """Pipelined runs of small batches rotate through four sets of bit planes, each hysteresis chain on a stream of its
+    own.  Whatever the number of output buffers the caller cycles through -- a run into memory that an older run still
+    in flight writes must wait for it -- every buffer ends up holding the map of the last run that wrote it; then the
+    same context takes a big batch (back to the two-slot ring) and small ones again."""
+    import torch
+    w, h, nb = 640, 200, 2
+    runs = [np.stack([synth.natural(w, h, 300 + 7 * r + f) if (r + f) % 3 else synth.serpentine(w, h, amp=20, seed_amp=120) for f in range(nb)]) for r in range(11)]
+    want = [oracle.canny_r_batch(b, 10, 40, threads=4) for b in runs]
+    d_in = [torch.from_numpy(b).cuda() for b in runs]
+    d_out = [torch.zeros((nb, h, w), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
+    big = np.stack([synth.natural(w, h, 900 + f) for f in range(1400)])   # 280 k frame rows: the two-slot ring
+    with api.Context(w, h, 1, 1400) as ctx:
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        for rep in range(2):
+            last = {}
+            for r in range(len(runs)):
+                ctx.run_device(d_in[r].data_ptr(), w, w * h, d_out[r % nbuf].data_ptr(), w, w * h, nb)
+                last[r % nbuf] = r
+            ctx.sync()
+            for b, r in last.items():
+                got = d_out[b].cpu().numpy()
+                for f in range(nb):
+                    _diff(got[f], want[r][f], f"{nbuf} buffers, rep {rep}, run {r}, frame {f}")
+            if rep == 0:
+                got = ctx.process(big)
+                for f in (0, 700, 1399):
+                    _diff(got[f], oracle.canny_r(big[f], 10, 40), f"big batch between the small ones, frame {f}")
+
+
 def test_python_mirror_of_reference_operator(oracle):
     img = synth.natural(320, 200, 31)
     pipe = api.cvPipeline(0, 320, 200, 1)
