@@ -118,7 +118,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     n_out = 3 * B if a.per_channel else B
     # two output batches used in turn, as a pipelined consumer would (run i's maps are read while run i+1 computes);
     # with a single one the library falls back to the non-provisional expand to keep run i+1's map intact
-    d_outs = [torch.empty((n_out, H, W), dtype=torch.uint8, device=dev) for _ in range(1 if a.no_pipeline else (a.out_buffers or (4 if n_out * H < 256 * 1024 else 2)))]
+    d_outs = [torch.empty((n_out, H, W), dtype=torch.uint8, device=dev) for _ in range(1 if a.no_pipeline else (a.out_buffers or (4 if n_out * H * W < 500e6 else 2)))]
     d_out = d_outs[0]
     del d_u
 

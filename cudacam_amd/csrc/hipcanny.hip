@@ -423,9 +423,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   const int n_out = c->per_channel ? 3 * n : n;  // output frames (= bit-plane frames)
   const bool piped = c->pipeline && stage == HC_STAGE_HYSTER;
   if (piped) {
-    // big batches rotate through two slots, small ones (the step is the latency of the hysteresis chain) through four
+    // big batches rotate through two slots, small ones (fewer than 0.5 G pixels per run: the step is the latency of the
+    // hysteresis chain) through four
     // (measured at 1080p: 128 frames per run 237 against 218 k frames/s with four, 256 frames 301 against 310 k)
-    const int use = (long)n_out * H < 256 * 1024 ? NSLOT : 2;
+    const int use = (long long)n_out * H * W < 500ll * 1000 * 1000 ? NSLOT : 2;  // by pixels: 16 8K x 3 frames are a big batch
     if (use != c->nslot_use) {
       if (int rc = finish_all(c)) return rc;
       c->nslot_use = use;

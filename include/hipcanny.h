@@ -153,7 +153,7 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * run sees what the caller queued before it and the input may be reused by work queued after it; the OUTPUT
  * of a run is only guaranteed after hc_sync() (or hc_download).  Results are identical in both modes.  Hand
  * consecutive runs different output buffers -- two in turn for big batches, four for small ones (fewer than
- * 256 Ki frame rows per run: there four runs are kept in flight, each hysteresis on a stream of its own, because a
+ * 0.5 G pixels per run: there four runs are kept in flight, each hysteresis on a stream of its own, because a
  * step is otherwise the latency of the hysteresis' chain of launches).  A run whose output overlaps that of a run
  * still in flight waits for it, and if that is the previous run it still gives the exact map, but without the
  * provisional-map shortcut and a few percent slower.
