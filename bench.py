@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames in the CPU baseline sample (0 = auto)")
     ap.add_argument("--sweep", action="store_true", help="one JSON line per batch size in {1, 8, 64, 256, 1024} (SURVEY 8d C2) instead of the single headline line")
+    ap.add_argument("--sweep-batches", default="1,8,64,256,1024", help="the batch sizes of --sweep")
     ap.add_argument("--no-host-fed", action="store_true", help="skip the bounded host-fed (PCIe-inclusive) end-to-end leg")
     return ap.parse_args()
 
@@ -83,7 +84,7 @@ def main():
     if a.sweep:
         if world != 1:
             raise SystemExit("--sweep is a single-GPU measurement")
-        for b in (1, 8, 64, 256, 1024):
+        for b in [int(x) for x in a.sweep_batches.split(",")]:
             a.batch = b
             a.steps_eff = max(a.steps, min(2000, 20480 // b))   # small batches: enough steps for a stable mean
             run_config(a, torch, dist, world, rank, local, backend, brief=True)
