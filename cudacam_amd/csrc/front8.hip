@@ -1,4 +1,5 @@
-// front8.hip -- k_front8: the WHOLE front path of the detector as one kernel, 8 pixels per lane.
+// front8.hip -- k_front8: the WHOLE front path of the detector as one kernel, 8 pixels per lane (Mode R); and k_front8o, the
+// cv::Canny-semantics (Mode O) kernel on the same skeleton (second half of the file).
 //
 // Replaces, in one launch and with no intermediate plane in HBM, the reference's rgb2mono, gaussianFilter5x5, sobelXY,
 // gradSlope, nonMaxSuppr and doubleThreshold kernels (src/cvp/cannyEdgeD.cu:53-293; launch sites
