@@ -117,18 +117,19 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     reps = (B + d_u.shape[0] - 1) // d_u.shape[0]
     d_in = d_u.repeat(*([reps] + [1] * (d_u.dim() - 1)))[:B].contiguous()   # (B, H, W[, 3]) u8, tight pitch
     n_out = 3 * B if a.per_channel else B
-    # two output batches used in turn, as a pipelined consumer would (run i's maps are read while run i+1 computes);
-    # with a single one the library falls back to the non-provisional expand to keep run i+1's map intact
-    d_outs = [torch.empty((n_out, H, W), dtype=torch.uint8, device=dev) for _ in range(1 if a.no_pipeline else (a.out_buffers or (4 if n_out * H * W < 500e6 else 2)))]
+    # output batches used in turn, as a pipelined consumer would (run i's maps are read while run i+1 computes): as many
+    # as the context keeps runs in flight (hc_pipeline_depth: 2, or 4 for small batches); with a single one the library
+    # falls back to the non-provisional expand to keep run i+1's map intact
+    ctx = api.Context(W, H, C, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local)
+    ctx.set_option(api.OPT_PIPELINE, 0 if a.no_pipeline else 1)
+    if a.per_channel:
+        ctx.set_option(api.OPT_PER_CHANNEL, 1)
+    d_outs = [torch.empty((n_out, H, W), dtype=torch.uint8, device=dev) for _ in range(1 if a.no_pipeline else (a.out_buffers or ctx.pipeline_depth(B)))]
     d_out = d_outs[0]
     del d_u
 
-    ctx = api.Context(W, H, C, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local)
-    if a.per_channel:
-        ctx.set_option(api.OPT_PER_CHANNEL, 1)
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
-    ctx.set_option(api.OPT_PIPELINE, 0 if a.no_pipeline else 1)
     ctx.set_option(api.OPT_FRONT_SPLIT, {"front8": 2, "split": 1, "fused4": 0}[a.front])   # (Mode O: front8 = k_front8o, the others = the 4-px k_front_o)
     # the context keeps its own (non-blocking) stream: the inputs were produced before the synchronize below, and the
     # timed region is bracketed by hc_sync + torch.cuda.synchronize, so no ordering with torch's stream is needed

@@ -52,7 +52,7 @@ ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
-    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals", "hc_last_run_info",
+    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals", "hc_last_run_info", "hc_pipeline_depth",
 ]
 
 _lib = None
@@ -114,6 +114,7 @@ def load_library():
     L.hc_selftest.argtypes = [i]
     L.hc_debug_tap.argtypes = [vp, i, vp, sz, sz, i]
     L.hc_last_run_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
+    L.hc_pipeline_depth.argtypes = [vp, i]
     L.hc_profile_get_intervals.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(i)]
     L.hc_host_alloc.restype = vp
     L.hc_host_alloc.argtypes = [sz]
@@ -242,6 +243,13 @@ class Context:
     def hysteresis_device(self, d_thr, in_pitch, in_fs, d_out, out_pitch, out_fs, nframes):
         _ck(self.lib.hc_hysteresis_device(self.handle, C.c_void_p(d_thr), in_pitch, in_fs, C.c_void_p(d_out), out_pitch,
                                           out_fs, int(nframes)))
+
+    def pipeline_depth(self, nframes):
+        """Runs of `nframes` frames kept in flight in pipelined mode (hc_pipeline_depth): the size of the output-buffer ring."""
+        r = self.lib.hc_pipeline_depth(self.handle, int(nframes))
+        if r < 0:
+            _ck(r)
+        return r
 
     def last_run_info(self):
         """(input_staged, output_staged, front_form) of the last run: see hc_last_run_info."""

@@ -252,6 +252,9 @@ int copy_frames_d2d(hc_ctx *c, hipStream_t st, void *dst, size_t dpitch, size_t 
   return HC_OK;
 }
 
+// slots the pipelined runs of n_out output frames rotate through: by pixels (16 8K x 3 frames are a big batch)
+int pipeline_slots(const hc_ctx *c, int n_out) { return (long long)n_out * c->H * c->W < 500ll * 1000 * 1000 ? NSLOT : 2; }
+
 // Completes a queued fused run: waits for it, and if its queued hysteresis launches did not reach
 // the fixpoint (flag of the last one still set -- adversarial inputs only), keeps iterating, then
 // redoes the expand.
@@ -426,7 +429,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     // big batches rotate through two slots, small ones (fewer than 0.5 G pixels per run: the step is the latency of the
     // hysteresis chain) through four
     // (measured at 1080p: 128 frames per run 237 against 218 k frames/s with four, 256 frames 301 against 310 k)
-    const int use = (long long)n_out * H * W < 500ll * 1000 * 1000 ? NSLOT : 2;  // by pixels: 16 8K x 3 frames are a big batch
+    const int use = pipeline_slots(c, n_out);
     if (use != c->nslot_use) {
       if (int rc = finish_all(c)) return rc;
       c->nslot_use = use;
@@ -1061,6 +1064,13 @@ int hc_debug_tap(hc_ctx *c, int what, uint8_t *host, size_t row_stride, size_t f
       HIPCK(hipMemcpy2D(host + frame_stride * f, row_stride, c->dbg_blur + c->out_fs * f, c->out_pitch, (size_t)W, (size_t)H, hipMemcpyDeviceToHost));
   }
   return HC_OK;
+}
+
+int hc_pipeline_depth(hc_ctx *c, int nframes)
+{
+  if (!c || nframes <= 0) return fail(HC_E_ARG, "hc_pipeline_depth: null context or nframes <= 0");
+  if (!c->pipeline) return 1;
+  return pipeline_slots(c, c->per_channel ? 3 * nframes : nframes);
 }
 
 int hc_last_run_info(hc_ctx *c, int *input_staged, int *output_staged, int *front_form)

@@ -132,6 +132,12 @@ int hc_last_hysteresis_info(hc_ctx *ctx, int *launches_with_work, int *continued
  * when a row does not hold whole 8-pixel groups. */
 int hc_last_run_info(hc_ctx *ctx, int *input_staged, int *output_staged, int *front_form);
 
+/* Pipelined mode: how many runs of `nframes` frames the context keeps in flight (2, or 4 for small batches -- fewer
+ * than 0.5 G pixels per run; 1 when HC_OPT_PIPELINE is off): the number of output buffers a caller should rotate
+ * through so that no run has to wait for an older one that still writes the same memory.  No reference counterpart
+ * (the reference processes one frame per synchronous call, src/cvp/cannyEdgeH.cu:49-120). */
+int hc_pipeline_depth(hc_ctx *ctx, int nframes);
+
 /* Diagnostics of the last run's queued hysteresis launches: 3 words per launch
  * (sweeps summed over tiles, max sweeps of a tile, tiles that did work). */
 int hc_hysteresis_stats(hc_ctx *ctx, unsigned *stats, int nwords);

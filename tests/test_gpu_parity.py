@@ -435,9 +435,11 @@ def test_small_batches_keep_four_runs_in_flight(oracle, nbuf):
     want = [oracle.canny_r_batch(b, 10, 40, threads=4) for b in runs]
     d_in = [torch.from_numpy(b).cuda() for b in runs]
     d_out = [torch.zeros((nb, h, w), dtype=torch.uint8, device="cuda") for _ in range(nbuf)]
-    big = np.stack([synth.natural(w, h, 900 + f) for f in range(1400)])   # 280 k frame rows: the two-slot ring
-    with api.Context(w, h, 1, 1400) as ctx:
+    big = np.tile(np.stack([synth.natural(w, h, 900 + f) for f in range(40)]), (100, 1, 1))   # 4000 frames = 0.51 G pixels: the two-slot ring
+    with api.Context(w, h, 1, 4000) as ctx:
+        assert ctx.pipeline_depth(nb) == 1
         ctx.set_option(api.OPT_PIPELINE, 1)
+        assert ctx.pipeline_depth(nb) == 4 and ctx.pipeline_depth(1400) == 4 and ctx.pipeline_depth(4000) == 2   # 0.5 G pixels = 3906 of these frames
         for rep in range(2):
             last = {}
             for r in range(len(runs)):
@@ -450,7 +452,7 @@ def test_small_batches_keep_four_runs_in_flight(oracle, nbuf):
                     _diff(got[f], want[r][f], f"{nbuf} buffers, rep {rep}, run {r}, frame {f}")
             if rep == 0:
                 got = ctx.process(big)
-                for f in (0, 700, 1399):
+                for f in (0, 1700, 3999):
                     _diff(got[f], oracle.canny_r(big[f], 10, 40), f"big batch between the small ones, frame {f}")
 
 
