@@ -31,6 +31,10 @@ HBM_PEAK_GBPS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.
 HBM_MEASURED_COPY_GBPS = 6290.0
 
 
+# hc_last_run_info's front form -> (config name, kernel name)
+FORM_NAME = {2: ("front8", "k_front8"), 1: ("split", "k_blur+k_nms"), 0: ("fused4", "k_front"), 3: ("k_front8o", "k_front8o"), -1: ("k_front_o", "k_front_o")}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -43,7 +47,7 @@ def parse():
     ap.add_argument("--hyst-launches", type=int, default=0, help="hysteresis launches queued per run (0 = auto)")
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
     ap.add_argument("--out-buffers", type=int, default=0, help="pipelined mode: output buffers used in turn (a run into memory that an earlier, still unfinished run writes waits for that run); 0 = as many as the context keeps runs in flight: 2, or 4 for small batches")
-    ap.add_argument("--front", default="front8", choices=["front8", "split", "fused4"], help="front path (HC_OPT_FRONT_SPLIT): front8 = one kernel, 8 px per lane (default; Mode O: k_front8o); split = k_blur + k_nms; fused4 = the 4-px fused kernel (Mode O: both = k_front_o)")
+    ap.add_argument("--front", default=None, choices=["front8", "split", "fused4"], help="front path (HC_OPT_FRONT_SPLIT): front8 = one kernel, 8 px per lane (default; Mode O: k_front8o); split = k_blur + k_nms; fused4 = the 4-px fused kernel (Mode O: both = k_front_o)")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3], help="3: interleaved BGR input (grey conversion fused into the load)")
     ap.add_argument("--per-channel", action="store_true", help="with --channels 3: one edge map per channel (BASELINE configs[4])")
@@ -130,7 +134,8 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
 
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
-    ctx.set_option(api.OPT_FRONT_SPLIT, {"front8": 2, "split": 1, "fused4": 0}[a.front])   # (Mode O: front8 = k_front8o, the others = the 4-px k_front_o)
+    if a.front is not None:   # (unset: the library's choice -- k_front8 / k_front8o, the 4-px pair for narrow frames)
+        ctx.set_option(api.OPT_FRONT_SPLIT, {"front8": 2, "split": 1, "fused4": 0}[a.front])   # (Mode O: front8 = k_front8o, the others = the 4-px k_front_o)
     # the context keeps its own (non-blocking) stream: the inputs were produced before the synchronize below, and the
     # timed region is bracketed by hc_sync + torch.cuda.synchronize, so no ordering with torch's stream is needed
 
@@ -196,11 +201,11 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
             "config": {"workload": (f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU" if (W, H, a.mode) == (1920, 1080, "R")
                                     else f"{W}x{H} " + ("grayscale" if C == 1 else "BGR, per-channel Canny" if a.per_channel else "BGR -> grey") + f", mode {a.mode}, batch {B} frames/step/GPU"),
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",
-                       "pipeline": not a.no_pipeline, "front": a.front if a.mode == "R" else ("k_front8o" if a.front == "front8" and a.channels == 1 else "k_front_o"),
+                       "pipeline": not a.no_pipeline, "front": FORM_NAME.get(front_form, ("?", "?"))[0],
                        "world_size": world, "backend": backend},
             "e2e_alg_GBps": round(alg_bytes_per_frame * frames_total / elapsed / 1e9, 1),
             "roofline": {
-                "bound": "hbm", "kernel": {"front8": "k_front8", "split": "k_blur+k_nms", "fused4": "k_front"}[a.front] if a.mode == "R" else ("k_front8o" if a.front == "front8" and a.channels == 1 else "k_front_o"), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "bound": "hbm", "kernel": FORM_NAME.get(front_form, ("?", "?"))[1], "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "frac_of_measured_copy": round(achieved / HBM_MEASURED_COPY_GBPS, 4),
                 "traffic": None, "kernel_ms": round(front_ms, 4),
                 "kernel_ms_each": ({"k_blur": round(ksums[0] / kruns, 4), "k_nms": round(ksums[1] / kruns, 4)} if kruns else None),

@@ -86,6 +86,7 @@ struct hc_ctx {
   int hyst_late_grid = 0;              // diagnostics (HC_HYST_LATE_GRID): workgroups of the hysteresis launches >= 1
   int hyst_obs[3] = { 0, 0, 0 };       // hysteresis launches the last runs needed with base_waves << i waves per workgroup (0: not seen)
   int hyst_obs_base = 0, hyst_obs_rows = 0;  // the base shape those observations belong to
+  bool split_set = false;  // HC_OPT_FRONT_SPLIT was set by the caller
   int split = 2;        // Mode R front path: 2 = k_front8 (one kernel, 8 px per lane; default), 1 = k_blur + k_nms, 0 = the 4-px fused k_front
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
   uint8_t *d_dump = nullptr;    // k_front8's dump area (FrontParams::dump), followed by its page of zeros (FrontParams::zeros)
@@ -520,7 +521,12 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     const bool can8 = sp >= round_up((size_t)W, 8) * (size_t)(fuse_bgr || c->per_channel ? 3 : 1);
     // Mode O: k_front8o (form 3) for one-channel sources, the 4-px k_front_o (form -1) for 3-channel ones, for rows that
     // do not hold whole 8-pixel groups, or when HC_OPT_FRONT_SPLIT asks for a 4-px form
-    const int form = c->mode != HC_MODE_R ? ((c->C == 1 && c->split == 2 && can8) ? 3 : -1) : (c->split == 2 && !can8) ? 1 : c->split;
+    // Narrow frames: a wave of k_front8 covers 496 columns whether or not they exist -- 640 columns cost two waves' worth
+    // (62.5 % of the lanes) -- while the 4-px kernels' strips are 248 columns wide (three strips, 83 %), at about 1.1 x
+    // the cost per lane: unless the caller chose a form, k_blur + k_nms take the widths where that pays (640 x 480:
+    // 1.61 against 1.32 M frames/s; 800 x 600 and 1280 x 720: k_front8 stays, 1.15 against 1.04 M and 729 against 658 k)
+    const bool narrow4 = c->mode == HC_MODE_R && !c->split_set && ((W + 247) / 248) * 256 * 110 < ((W + 495) / 496) * 512 * 90;  // (at least 7 % predicted)
+    const int form = c->mode != HC_MODE_R ? ((c->C == 1 && c->split == 2 && can8) ? 3 : -1) : (c->split == 2 && (!can8 || narrow4)) ? 1 : c->split;
     const bool split = form == 1, f8 = form == 2 || form == 3;
     c->last_front_form = form;
     // Pipelined mode: k_nms / k_front_o also write the strong pixels as 255 into the output (4 px per lane: whole
@@ -836,6 +842,7 @@ int hc_set_option(hc_ctx *c, int option, int value)
   } else if (option == HC_OPT_FRONT_SPLIT) {
     if (value < 0 || value > 2) return fail(HC_E_ARG, "HC_OPT_FRONT_SPLIT: 0 (k_front), 1 (k_blur + k_nms) or 2 (k_front8)");
     c->split = value;
+    c->split_set = true;  // the caller's choice: no automatic switch to the 4-px pair for narrow frames
   } else if (option == HC_OPT_L2_GRADIENT) {
     if (c->mode != HC_MODE_O) return fail(HC_E_ARG, "HC_OPT_L2_GRADIENT applies to mode O contexts");
     c->l2gradient = value != 0;

@@ -292,7 +292,7 @@ def test_run_device_unaligned_and_torch_stream(oracle):
         ctx.run_device(d_in.data_ptr(), 641, 641 * 479, d_out.data_ptr(), 641, 641 * 479, 1)
         ctx.sync()
         _diff(d_out.cpu().numpy(), want, "unaligned run_device")
-        assert ctx.last_run_info() == (True, True, 2)   # both buffers went through the internal pitched ones: reported, not hidden
+        assert ctx.last_run_info() == (True, True, 1)   # both buffers went through the internal pitched ones: reported, not hidden (641 columns: the 4-px pair)
         # a side stream of the caller: producer and detector on it, no host synchronisation in between
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
@@ -617,8 +617,22 @@ def test_last_run_info_reports_form_and_staging(oracle):
     with api.Context(640, 100, 1, 1) as ctx:
         ctx.run_device(d_in.data_ptr(), 640, 640 * 100, d_out.data_ptr(), 640, 640 * 100, 1)
         ctx.sync()
+        assert ctx.last_run_info() == (False, False, 1)   # 640 columns: the 4-px pair fills its strips better (automatic while the option is unset)
+        _diff(d_out.cpu().numpy(), oracle.canny_r(img, 10, 40), "in place, narrow frame")
+        ctx.set_option(api.OPT_FRONT_SPLIT, 2)
+        ctx.run_device(d_in.data_ptr(), 640, 640 * 100, d_out.data_ptr(), 640, 640 * 100, 1)
+        ctx.sync()
         assert ctx.last_run_info() == (False, False, 2)
         _diff(d_out.cpu().numpy(), oracle.canny_r(img, 10, 40), "in place")
+    img8 = synth.natural(800, 60, 5)
+    d_in8 = torch.from_numpy(img8).cuda()
+    d_out8 = torch.zeros_like(d_in8)
+    torch.cuda.synchronize()
+    with api.Context(800, 60, 1, 1) as ctx:
+        ctx.run_device(d_in8.data_ptr(), 800, 800 * 60, d_out8.data_ptr(), 800, 800 * 60, 1)
+        ctx.sync()
+        assert ctx.last_run_info() == (False, False, 2)
+        _diff(d_out8.cpu().numpy(), oracle.canny_r(img8, 10, 40), "in place, 800 columns")
     img2 = synth.natural(644, 60, 4)   # pitch 644: a multiple of 4 but not of 8
     d_in2 = torch.from_numpy(img2).cuda()
     d_out2 = torch.zeros_like(d_in2)
