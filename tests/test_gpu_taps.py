@@ -169,3 +169,19 @@ def test_mode_o_three_channel_device_buffers(oracle):
         ctx.run_device(d_in.data_ptr(), 303, 303 * 77, d_out.data_ptr(), 101, 101 * 77, 1)
         ctx.sync()
     _diff(d_out.cpu().numpy(), oracle.canny_o(img, 50, 150), "mode O 3-channel, unaligned device buffers")
+
+
+@pytest.mark.parametrize("w,h,form", [(640, 480, 1), (200, 120, 1), (744, 60, 1), (745, 60, 2), (496, 60, 2), (1280, 90, 2)])
+def test_default_form_by_width(oracle, w, h, form):
+    """While HC_OPT_FRONT_SPLIT is unset the library picks the front form by how well the width fills the strips: the 4-px
+    pair (248-column strips) up to 248 and for 497..744 columns, k_front8 (496-column strips) otherwise -- the same blur,
+    bit planes and edges either way."""
+    img = synth.natural(w, h, 5 + w)
+    blur, thr, edges = _want(oracle, img, 10, 40)
+    with api.Context(w, h, 1, 1) as ctx:
+        ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+        got = ctx.process(img)[0]
+        assert ctx.last_run_info()[2] == form
+        _diff(ctx.debug_tap(api.TAP_BLUR)[0], blur, f"{w}x{h}: blur")
+        _diff(ctx.debug_tap(api.TAP_THRESH)[0], thr, f"{w}x{h}: bit planes")
+        _diff(got, edges, f"{w}x{h}: edges")
