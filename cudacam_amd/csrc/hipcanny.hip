@@ -525,7 +525,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     // (62.5 % of the lanes) -- while the 4-px kernels' strips are 248 columns wide (three strips, 83 %), at about 1.1 x
     // the cost per lane: unless the caller chose a form, k_blur + k_nms take the widths where that pays (640 x 480:
     // 1.61 against 1.32 M frames/s; 800 x 600 and 1280 x 720: k_front8 stays, 1.15 against 1.04 M and 729 against 658 k)
-    const bool narrow4 = c->mode == HC_MODE_R && !c->split_set && ((W + 247) / 248) * 256 * 110 < ((W + 495) / 496) * 512 * 90;  // (at least 7 % predicted)
+    // -- for big batches only: one VGA frame per call takes 0.106 ms through k_front8 and 0.154 ms through the pair (two
+    // launches instead of one, and a blur plane between them)
+    const bool narrow4 = c->mode == HC_MODE_R && !c->split_set && (long long)n_out * H * W >= 100ll * 1000 * 1000
+                         && ((W + 247) / 248) * 256 * 110 < ((W + 495) / 496) * 512 * 90;  // (at least 7 % predicted)
     const int form = c->mode != HC_MODE_R ? ((c->C == 1 && c->split == 2 && can8) ? 3 : -1) : (c->split == 2 && (!can8 || narrow4)) ? 1 : c->split;
     const bool split = form == 1, f8 = form == 2 || form == 3;
     c->last_front_form = form;

@@ -172,8 +172,8 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * HC_OPT_FRONT_SPLIT (default 2, Mode R): which kernels form the front path (grey | blur | Sobel | NMS | thresholds).
  * 2 = k_front8: ONE kernel, 8 pixels per lane, no intermediate in HBM (falls back to 1 when an input row does not hold
  * whole 8-pixel groups, i.e. pitch < round_up(width, 8) * channels; and, while the option has not been set by the
- * caller, for narrow frames whose width fills the 248-column strips of the 4-px kernels much better than the
- * 496-column strips of k_front8: up to 248 columns and 497..744 (VGA)); 1 = k_blur + k_nms with a u8 blur plane between
+ * caller, for big batches (0.1 G pixels or more per run) of narrow frames whose width fills the 248-column strips of
+ * the 4-px kernels much better than the 496-column strips of k_front8: up to 248 columns and 497..744 (VGA)); 1 = k_blur + k_nms with a u8 blur plane between
  * them; 0 = k_front, the earlier 4-pixel fused kernel.  Results are identical; 0 and 1 are kept as independent
  * implementations for the parity tests.  Mode O contexts: 2 = k_front8o, the 8-pixel kernel (one-channel sources;
  * 3-channel sources and rows without whole 8-pixel groups use k_front_o), 0 or 1 = k_front_o, the 4-pixel kernel.

@@ -171,17 +171,20 @@ def test_mode_o_three_channel_device_buffers(oracle):
     _diff(d_out.cpu().numpy(), oracle.canny_o(img, 50, 150), "mode O 3-channel, unaligned device buffers")
 
 
-@pytest.mark.parametrize("w,h,form", [(640, 480, 1), (200, 120, 1), (744, 60, 1), (745, 60, 2), (496, 60, 2), (1280, 90, 2)])
-def test_default_form_by_width(oracle, w, h, form):
-    """While HC_OPT_FRONT_SPLIT is unset the library picks the front form by how well the width fills the strips: the 4-px
-    pair (248-column strips) up to 248 and for 497..744 columns, k_front8 (496-column strips) otherwise -- the same blur,
-    bit planes and edges either way."""
-    img = synth.natural(w, h, 5 + w)
-    blur, thr, edges = _want(oracle, img, 10, 40)
-    with api.Context(w, h, 1, 1) as ctx:
+@pytest.mark.parametrize("w,h,nb,form", [(640, 480, 400, 1), (640, 480, 300, 2), (200, 120, 4200, 1), (744, 60, 2300, 1), (745, 60, 2300, 2), (496, 60, 3400, 2), (1280, 90, 900, 2)])
+def test_default_form_by_width(oracle, w, h, nb, form):
+    """While HC_OPT_FRONT_SPLIT is unset the library picks the front form by how well the width fills the strips: for big
+    batches (0.1 G pixels per run or more) the 4-px pair (248-column strips) up to 248 and for 497..744 columns, k_front8
+    (496-column strips) otherwise and for small batches -- the same blur, bit planes and edges either way."""
+    uniq = np.stack([synth.natural(w, h, 5 + w + k) for k in range(4)])
+    frames = np.tile(uniq, ((nb + 3) // 4, 1, 1))[:nb]
+    with api.Context(w, h, 1, nb) as ctx:
         ctx.set_option(api.OPT_DEBUG_TAPS, 1)
-        got = ctx.process(img)[0]
+        got = ctx.process(frames)
         assert ctx.last_run_info()[2] == form
-        _diff(ctx.debug_tap(api.TAP_BLUR)[0], blur, f"{w}x{h}: blur")
-        _diff(ctx.debug_tap(api.TAP_THRESH)[0], thr, f"{w}x{h}: bit planes")
-        _diff(got, edges, f"{w}x{h}: edges")
+        tb, tt = ctx.debug_tap(api.TAP_BLUR, nb), ctx.debug_tap(api.TAP_THRESH, nb)
+        for k in (0, 1, 2, 3, nb - 1):
+            blur, thr, edges = _want(oracle, frames[k], 10, 40)
+            _diff(tb[k], blur, f"{w}x{h} frame {k}: blur")
+            _diff(tt[k], thr, f"{w}x{h} frame {k}: bit planes")
+            _diff(got[k], edges, f"{w}x{h} frame {k}: edges")
