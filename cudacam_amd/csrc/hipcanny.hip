@@ -375,6 +375,9 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // at 8K: 70 launches queued, 50 of them idle at ~5 us each on the hysteresis stream) but what the last runs needed, + 4;
   // a frame that needs more is finished by the continuation, and the estimate follows it at once
   if (small_tiles && c->hyst_need_rows > 0) K = std::min(K, std::max(6, need + 4));
+  // (a few frames per run, pipelined: the step is the host's time to queue the run -- 75 us for ~25 API calls -- so every
+  // launch that is not needed counts)
+  if (small_tiles && c->hyst_need_rows > 0 && (long)n * c->H < 128 * 1024) K = std::min(K, std::max(4, need + 2));
   if (c->hyst_launches_set) K = c->hyst_launches;
   hp.out = out; hp.out_pitch = out_pitch; hp.out_frame_stride = out_fs; hp.W = c->W;
   // worklists of launches >= 1: counts and reason words live behind the launch flags and are zeroed with them
