@@ -68,7 +68,7 @@ struct HystParams {
   u32 *wl_reason;  // [2][wl_stride] per tile: 1 a tile above changed (its `top`), 2 below, 4 beside; zero at the start of a run
   u32 *wl_list;    // [2][wl_stride] wide frames: tile ids (frame * tiles per frame + tile)
   size_t wl_stride;
-  int lists;       // 1: launches >= 1 take their tiles from the worklists (k_hyst MODE 1 / 2); 0: a workgroup per tile in every launch (MODE 0)
+  int lists;       // this launch: 1 takes its tiles from the worklist (k_hyst MODE 1 / 2); 0 a workgroup per tile (MODE 0); 2 a workgroup per tile that also writes the next launch's list (MODE 3)
   int late_grid;   // worklist scheme: workgroups of launches >= 1 (0 = by the tile count, launch_hyst)
   int iter;        // index of this launch
   u32 *stats;      // optional diagnostics (3 words per launch) or null

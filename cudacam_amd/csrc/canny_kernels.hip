@@ -1571,7 +1571,8 @@ void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, 
 template <int NW, int TR, int WAVES, bool PANELS, int MODE>
 static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile, bool top, bool bot, bool side)
 {
-  const bool LATE = MODE == 0 ? p.iter > 0 : MODE == 2;
+  constexpr bool WORDS_IN = MODE == 0 || MODE == 3;  // the tile finds its reason in its word (a workgroup per tile); MODE 3 also writes lists: the launch before the first list launch
+  const bool LATE = WORDS_IN ? p.iter > 0 : MODE == 2;
   static_assert(NW == 1, "frames wider than one panel are tiled in column panels; a lane holds one dword per row");
   static_assert((TR & (TR - 1)) == 0, "row indices are wrapped with TR - 1");
   constexpr int ROWW = 64 * NW;  // dwords per row
@@ -1589,7 +1590,7 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
   const int H = p.H, RD = p.RD;
   const int pcol = pn * ROWW;                          // first dword of this panel in a plane row
   const int b0 = bt * BR, nb = min(H, b0 + BR) - b0;  // rows of this workgroup tile
-  if (MODE == 0 && LATE) {
+  if (WORDS_IN && LATE) {
     // work only if a neighbouring tile changed the row / column / corner this tile looks at: it left its reason in this
     // tile's word of the launch's parity (one load; cleared for the launch after next)
     u32 *reason = p.wl_reason + (size_t)(p.iter & 1) * p.wl_stride;
@@ -2026,7 +2027,7 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
 template <int NW, int TR, int WAVES, bool PANELS, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
 {
-  if (MODE == 0 && p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
+  if ((MODE == 0 || MODE == 3) && p.iter > 0 && p.flags[p.iter - 1] == 0) return;  // previous launch changed no tile boundary: fixpoint reached
   // latency-bound kernel (a few waves walking dependent row steps): when it shares a SIMD with the next
   // run's front waves (pipelined mode) it should win the instruction arbitration
   __builtin_amdgcn_s_setprio(3);
@@ -2061,9 +2062,9 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   if (p.RD > 256) return hipErrorInvalidValue;
   if (p.npanels != (p.RD + 63) / 64 || p.RD % 64) return hipErrorInvalidValue;
   const size_t tiles = (size_t)p.nframes * p.nrtiles * p.npanels;
-  const bool wide = p.npanels > 1, late = p.iter > 0, lists = p.lists != 0;
+  const bool wide = p.npanels > 1, late = p.iter > 0, lists = p.lists == 1;
   if (tiles > 0x7FFFFFFFull || !p.wl_reason || p.wl_stride < tiles) return hipErrorInvalidValue;
-  if ((wide || lists) && (!p.wl_count || !p.wl_list)) return hipErrorInvalidValue;
+  if ((wide || p.lists != 0) && (!p.wl_count || !p.wl_list)) return hipErrorInvalidValue;
   // a workgroup per tile -- except the later launches of the worklist scheme: a workgroup per list entry.  Grid: the
   // caller's (p.late_grid, from the last run's list lengths), or a schedule that shrinks to an eighth of the tiles (at
   // least 2048 workgroups): on camera-like frames a third of the tiles are listed for launch 1, 1-2 % from launch 5 on;
@@ -2076,7 +2077,8 @@ hipError_t launch_hyst(const HystParams &p, hipStream_t s)
   const dim3 grid((unsigned)wgs), block(64 * g.waves);
 #define HC_HYST_LAUNCH_P(TR_, WAVES_, PANELS_)                                                             \
   {                                                                                                         \
-    if (!lists) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, PANELS_, 0>), grid, block, 0, s, p);             \
+    if (p.lists == 2) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, PANELS_, 3>), dim3((unsigned)tiles), block, 0, s, p); \
+    else if (!lists) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, PANELS_, 0>), grid, block, 0, s, p);        \
     else if (late) hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, PANELS_, 2>), grid, block, 0, s, p);          \
     else hipLaunchKernelGGL((k_hyst<1, TR_, WAVES_, PANELS_, 1>), grid, block, 0, s, p);                    \
   }

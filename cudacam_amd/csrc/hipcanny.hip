@@ -399,13 +399,20 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   c->hyst_lists_last = hp.lists != 0;
   hp.first_pass = 1;
   hp.prov = s.prov ? 1 : 0;
+  // The other streams: a workgroup per tile for launches 0 and 1 -- which do most of the work, and whose idle workgroups
+  // keep the hysteresis spread over the front kernel it runs beside -- then lists for the tail of launches that follow a
+  // few long edges through the frame (launch 2 still starts every tile, and writes the first list): 1080p grey 394 -> 405 k
+  // frames/s, 256 frames per run 307 -> 317 k; with the lists from launch 1 on: 400 k, from launch 4: 404 k.  (The list
+  // streams above keep their lists from launch 1: BGR 259 against 252 k, 8K x 3 8.76 against 8.64 k; 4K would gain 2 %.)
+  const int mixed_from = (!hp.lists && !c->hyst_late_grid && small_tiles) ? 2 : 0;
   for (int k = 0; k < K; ++k) {
     hp.iter = k;
     // worklist scheme, launches >= 1: a workgroup per list entry.  Grid: twice what the last run of this shape listed for
     // the launch (entries beyond the grid wait a launch: a dense frame would need several launches more); without such
     // a run, launch_hyst's schedule by the tile count
     hp.late_grid = c->hyst_late_grid > 0 ? c->hyst_late_grid : 0;
-    if (hp.lists && !hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>(2048, 2 * (size_t)c->wl_prev[k] + 256));
+    if (mixed_from > 0) hp.lists = k < mixed_from ? 0 : k == mixed_from ? 2 : 1;
+    if (hp.lists == 1 && !hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>(2048, 2 * (size_t)c->wl_prev[k] + 256));
     // diagnostics cost ~3 same-address atomics per wave (hundreds of microseconds per launch): opt-in only
     hp.stats = c->hyst_diag ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
     HIPCK(launch_hyst(hp, st));
