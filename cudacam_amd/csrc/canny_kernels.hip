@@ -1568,6 +1568,8 @@ void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, 
 //         neighbours that look at it to the next launch's list.
 // MODE 2: a later launch of the worklist scheme; the tile is on the list because a neighbour above / below / beside
 //         changed the row or column it looks at (top / bot / side).
+// MODE 3: as MODE 0, but the neighbours also go on the next launch's list: the launch between per-tile launches and list
+//         launches of a run that starts with the former and ends with the latter.
 template <int NW, int TR, int WAVES, bool PANELS, int MODE>
 static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile, bool top, bool bot, bool side)
 {
@@ -2010,8 +2012,8 @@ static __device__ __forceinline__ void hyst_tile(const HystParams &p, int gtile,
   }
 }
 
-// MODE 0 (frames of one column panel, up to 2048 columns; dense wide frames): a workgroup per tile in every launch; a
-// tile whose neighbours left it no reason exits after one load.
+// MODE 0 / 3 (frames of one column panel, up to 2048 columns; dense wide frames -- their launches 0 to 2): a workgroup per
+// tile; a tile whose neighbours left it no reason exits after one load.
 // MODE 1 / 2 (wider frames): launch 0 as above; launch k > 0 takes its tiles from the worklist its predecessor wrote --
 // the tiles whose neighbours changed a boundary row / column -- with a grid that is a fraction of the tile count
 // (launch_hyst), one list entry per workgroup.  With panels a tile has eight neighbours, the flag test of MODE 0 is nine
