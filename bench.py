@@ -42,7 +42,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=1024, help="frames per step per GPU (2 GiB in + 2 GiB out at 1080p; hysteresis is latency-bound, larger batches amortise it)")
     ap.add_argument("--unique", type=int, default=32, help="distinct synthetic frames (tiled to the batch; about 0.7 s of host time each at 1080p)")
-    ap.add_argument("--kind", default="natural", choices=["natural", "noise"])
+    ap.add_argument("--kind", default="natural", choices=["natural", "noise"], help="content of the single batch of --rotate 1")
+    ap.add_argument("--rotate", type=int, default=4, help="content rotation: the steps cycle through N DIFFERENT batches -- natural (seed set A), natural (seed set B), iid noise, "
+                    "three natural frames blended as BGR -> grey would -- so that the library's adaptive choices (hysteresis launches queued, tile height, worklists, grids) "
+                    "meet content they did not just see; 1 = the same batch every step (rounds 1-2)")
     ap.add_argument("--chunk", type=int, default=0)
     ap.add_argument("--hyst-launches", type=int, default=0, help="hysteresis launches queued per run (0 = auto)")
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
@@ -74,10 +77,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "HC_BENCH_LOCAL_DEVICE" in os.environ:   # tests: several ranks on ONE device (the 1-GPU box exercising the N > 1 launch path)
+        local = int(os.environ["HC_BENCH_LOCAL_DEVICE"])
     backend = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" IS RCCL on ROCm
+        backend = os.environ.get("HC_BENCH_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")   # "nccl" IS RCCL on ROCm
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
         # the launcher's world must be the one asked for: one rank per GPU, frames sharded over exactly --gpus devices
         assert dist.get_world_size() == a.gpus == world, f"--gpus {a.gpus} but the process group has {dist.get_world_size()} ranks"
@@ -112,14 +117,46 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
         raise SystemExit("--channels 3 needs a width that is a multiple of 4 (whole 12-byte pixel groups in a tight row)")
     if a.per_channel and a.mode != "R":
         raise SystemExit("--per-channel is a mode R option")
-    nu = min(a.unique, B)
-    if C == 1:
-        uniq = synth.frames(a.kind, W, H, nu, seed=synth.SEED0 + 1000 * rank)
-    else:   # three differently seeded planes interleaved as B, G, R
-        uniq = np.stack([synth.frames(a.kind, W, H, nu, seed=synth.SEED0 + 1000 * rank + 77 * c) for c in range(3)], axis=-1)
-    d_u = torch.from_numpy(np.ascontiguousarray(uniq)).to(dev)
-    reps = (B + d_u.shape[0] - 1) // d_u.shape[0]
-    d_in = d_u.repeat(*([reps] + [1] * (d_u.dim() - 1)))[:B].contiguous()   # (B, H, W[, 3]) u8, tight pitch
+    # ---- content: `rot` different batches, the steps cycle through them (every step of rounds 1-2 processed the
+    # same batch, so "what the last run needed" always predicted the next run perfectly) ------------------------------------
+    rot = max(1, a.rotate)
+    kinds = [a.kind] if rot == 1 else [("natural", "natural-B", "noise", "blend")[k % 4] for k in range(rot)]
+    nat_per = max(2, min(a.unique, B) // (3 if rot > 1 else 1))   # distinct natural frames per natural batch (0.7 s of host time each at 1080p)
+    seed_r = synth.SEED0 + 1000 * rank
+    _nat_cache = {}
+
+    def nat(seed_off, n):   # (n, H, W) natural frames, cached by seed offset
+        key = (seed_off, n)
+        if key not in _nat_cache:
+            _nat_cache[key] = synth.frames("natural", W, H, n, seed=seed_r + seed_off)
+        return _nat_cache[key]
+
+    def planes(kind, chan, bi):   # the distinct frames of one batch, one channel
+        off = 77 * chan + 100003 * (bi // 4)
+        if kind == "natural":
+            return nat(off, nat_per)
+        if kind == "natural-B":
+            return nat(off + 500, nat_per)
+        if kind == "noise":
+            return synth.frames("noise", W, H, 8, seed=seed_r + 9000 + off)
+        # "blend": what BGR -> grey makes of three unrelated natural planes (rgb2mono's weights, cannyEdgeD.cu:14-19) -- edges
+        # of three images overlaid, chains that wind through the tiles: the stream that needed 25 hysteresis launches in round 2
+        pa, pb = nat(off, nat_per).astype(np.uint32), nat(off + 500, nat_per).astype(np.uint32)
+        pc = np.roll(pa, nat_per // 2, axis=0)[:, ::-1, :]
+        return ((7 * pa + 38 * pb + 19 * pc) >> 6).astype(np.uint8)
+
+    d_ins = []
+    for bi, kind in enumerate(kinds):
+        if C == 1:
+            uniq = planes(kind, 0, bi)
+        else:   # three differently seeded planes interleaved as B, G, R
+            uniq = np.stack([planes(kind, c, bi) for c in range(3)], axis=-1)
+        d_u = torch.from_numpy(np.ascontiguousarray(uniq)).to(dev)
+        reps = (B + d_u.shape[0] - 1) // d_u.shape[0]
+        d_ins.append(d_u.repeat(*([reps] + [1] * (d_u.dim() - 1)))[:B].contiguous())   # (B, H, W[, 3]) u8, tight pitch
+        del d_u
+    _nat_cache.clear()
+    d_in = d_ins[0]
     n_out = 3 * B if a.per_channel else B
     # output batches used in turn, as a pipelined consumer would (run i's maps are read while run i+1 computes): as many
     # as the context keeps runs in flight (hc_pipeline_depth: 2, or 4 for small batches); with a single one the library
@@ -130,7 +167,6 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
         ctx.set_option(api.OPT_PER_CHANNEL, 1)
     d_outs = [torch.empty((n_out, H, W), dtype=torch.uint8, device=dev) for _ in range(1 if a.no_pipeline else (a.out_buffers or ctx.pipeline_depth(B)))]
     d_out = d_outs[0]
-    del d_u
 
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
@@ -143,8 +179,9 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
 
     def step():
         o = d_outs[nstep[0] % len(d_outs)]
+        src = d_ins[nstep[0] % len(d_ins)]
         nstep[0] += 1
-        ctx.run_device(d_in.data_ptr(), W * C, W * C * H, o.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
+        ctx.run_device(src.data_ptr(), W * C, W * C * H, o.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
 
     for _ in range(a.warmup):
         step()
@@ -152,6 +189,8 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     torch.cuda.synchronize(dev)
     ctx.enable_profiling(True)     # hipEvent pairs around the fused kernel, on the launch stream
     ctx.profile_get(reset=True)
+    ctx.hysteresis_totals(reset=True)
+    first_timed = nstep[0]
 
     if world > 1:
         dist.barrier()
@@ -167,11 +206,13 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     t1 = time.perf_counter()
     ksums, kruns = ctx.profile_get_front()
     intervals = ctx.profile_intervals(steps + 8)
+    front_each = ctx.profile_front_each(steps + 8)
+    h_runs, h_continued, h_work, h_queued = ctx.hysteresis_totals()
     sums, nruns = ctx.profile_get(reset=True)
     work_launches, continued = ctx.hysteresis_info()
     in_staged, out_staged, front_form = ctx.last_run_info()
 
-    elapsed = shard.reduce_max_seconds(t1 - t0, dist if world > 1 else None, dev)
+    elapsed = shard.reduce_max_seconds(t1 - t0, dist if world > 1 else None, dev if backend == "nccl" else None)   # (gloo reduces host tensors)
 
     if rank == 0:
         frames_total = B * steps * world
@@ -196,12 +237,14 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "u8",
-            "data": f"synthetic ({a.kind}, {min(a.unique, B)} distinct frames tiled to the batch)",
+            "data": (f"synthetic ({a.kind}, {d_ins and min(a.unique, B)} distinct frames tiled to the batch, the same batch every step)" if rot == 1 else
+                     f"synthetic, {rot} different batches in rotation ({', '.join(kinds)}); {nat_per} distinct frames per natural / blend batch, 8 per noise batch, tiled to the batch"),
+            "content_rotation": rot,
             "output_buffers": len(d_outs),
             "config": {"workload": (f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU" if (W, H, a.mode) == (1920, 1080, "R")
                                     else f"{W}x{H} " + ("grayscale" if C == 1 else "BGR, per-channel Canny" if a.per_channel else "BGR -> grey") + f", mode {a.mode}, batch {B} frames/step/GPU"),
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",
-                       "pipeline": not a.no_pipeline, "front": FORM_NAME.get(front_form, ("?", "?"))[0],
+                       "pipeline": not a.no_pipeline, "front": FORM_NAME.get(front_form, ("?", "?"))[0], "content_rotation": rot,
                        "world_size": world, "backend": backend},
             "e2e_alg_GBps": round(alg_bytes_per_frame * frames_total / elapsed / 1e9, 1),
             "roofline": {
@@ -211,7 +254,10 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
                 "kernel_ms_each": ({"k_blur": round(ksums[0] / kruns, 4), "k_nms": round(ksums[1] / kruns, 4)} if kruns else None),
                 "hyst_expand_ms": round(hyst_ms, 4), "launches_timed": nruns,
             },
-            "hysteresis": {"launches_with_work": work_launches, "continued": continued},
+            # `continued` = runs of the whole timed region that needed the host-side continuation (each one stalls the stream)
+            "hysteresis": {"launches_with_work": work_launches, "continued": h_continued, "runs": h_runs,
+                           "launches_with_work_mean": round(h_work / max(h_runs, 1), 2), "launches_queued_mean": round(h_queued / max(h_runs, 1), 2)},
+            "by_content": _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch),
             # the caller's buffers were used in place (no hidden staging copies) and the front path that actually ran
             "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form)},
         }
@@ -231,11 +277,36 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
             except (OSError, KeyError, ValueError):
                 pass
         if not brief and not a.no_cpu_baseline and C == 1 and world == 1:   # the CPU baseline is an N = 1 figure
-            out["cpu_baseline"] = cpu_baseline(a, d_in, d_out)
+            # (untimed) one more run per content into the first output buffer: the oracle checks a sample of EVERY batch of the rotation
+            ncheck = min(B, 16)
+            samples = []
+            for kind, src in zip(kinds, d_ins):
+                ctx.run_device(src.data_ptr(), W * C, W * C * H, d_out.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
+                ctx.sync()
+                samples.append((kind, src[:ncheck].cpu().numpy(), d_out[:ncheck].cpu().numpy()))
+            out["cpu_baseline"] = cpu_baseline(a, d_ins, samples)
         if not brief and not a.no_host_fed and world == 1:
             out["host_fed"] = host_fed(a, d_in)
         print(json.dumps(out), flush=True)
     ctx.close()
+
+
+def _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch):
+    """Per content kind: the steps that processed it (interval j ends with timed step j + 1), their median step time and
+    the front kernel's mean time on that content."""
+    if len(kinds) == 1:
+        return None
+    out = {}
+    for ki, kind in enumerate(kinds):
+        st = [intervals[j] for j in range(len(intervals)) if (first_timed + j + 1) % len(kinds) == ki]
+        fr = [front_each[j] for j in range(len(front_each)) if (first_timed + j) % len(kinds) == ki]
+        med = float(np.median(st)) if st else None
+        fm = float(np.mean(fr)) if fr else None
+        out[kind] = {"steps": len(fr), "step_ms_median": round(med, 4) if med else None, "step_ms_max": round(max(st), 4) if st else None,
+                     "frames_per_s": round(B / med * 1e3, 1) if med else None,
+                     "kernel_ms": round(fm, 4) if fm else None,
+                     "roofline_frac": round(alg_bytes_per_launch / (fm * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if fm else None}
+    return out
 
 
 def _percentiles(ms):
@@ -295,17 +366,20 @@ def host_fed(a, d_in):
             "pcie_GBps_each_way": round(frames * frame_in / dt / 1e9, 2), "note": "frames start and end in host memory; one staging thread"}
 
 
-def cpu_baseline(a, d_in, d_out):
+def cpu_baseline(a, d_ins, checks):
     """The oracle (a CPU port of the reference pipeline, kind "port") timed on the host cores on a bounded sample of the
-    same frames -- at 1 thread and at all the threads this process may use -- and the GPU output for that sample checked
-    against it; the cv::Canny restatement (Mode O) beside it; and a real OpenCV if this host happens to have one."""
+    benchmark's frames -- at 1 thread and at all the threads this process may use; the GPU output of a sample of every
+    batch of the rotation checked against it; the cv::Canny restatement (Mode O) beside it; and a real OpenCV if this host
+    happens to have one."""
     from oracle import oracle as O   # test infrastructure: only this leg may touch it
     O.build()
     # the GPU box gives one GPU a 16-core CPU share: size the OpenMP pool to it
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     n = a.cpu_frames or max(cores * 4, 16)
-    n = min(n, d_in.shape[0])
-    sample = d_in[:n].cpu().numpy()
+    # the timed sample: frames of every batch of the rotation in equal parts (what a step processes on average)
+    per = max(1, n // len(d_ins))
+    sample = np.concatenate([d[:per].cpu().numpy() for d in d_ins])
+    n = sample.shape[0]
     run = O.canny_r_batch if a.mode == "R" else O.canny_o_batch
     run(sample[:min(n, cores)], LOW, HIGH, threads=cores)   # warm the pages/threads
 
@@ -317,13 +391,13 @@ def cpu_baseline(a, d_in, d_out):
     ref, dt = timed(lambda f, t: run(f, LOW, HIGH, threads=t), sample, cores)
     n1 = max(2, min(n, 8))
     _, dt1 = timed(lambda f, t: run(f, LOW, HIGH, threads=t), sample[:n1], 1)
-    same = bool(np.array_equal(ref, d_out[:n].cpu().numpy()))
+    same = {kind: bool(np.array_equal(run(src, LOW, HIGH, threads=cores), got)) for kind, src, got in checks}
     other = O.canny_o_batch if a.mode == "R" else O.canny_r_batch
     olo, ohi = (50, 150) if a.mode == "R" else (10, 40)
     _, dto = timed(lambda f, t: other(f, olo, ohi, threads=t), sample, cores)
     out = {"value": round(n / dt, 2), "unit": "frames/s", "cores": cores, "kind": "port",
-           "sample": f"{n} of the benchmark's {W}x{H} frames, OpenMP over frames, oracle/canny_oracle.c ({'orc_canny_r' if a.mode == 'R' else 'orc_canny_o'})",
-           "gpu_output_matches": same,
+           "sample": f"{n} of the benchmark's {W}x{H} frames ({per} of each batch of the rotation), OpenMP over frames, oracle/canny_oracle.c ({'orc_canny_r' if a.mode == 'R' else 'orc_canny_o'})",
+           "gpu_output_matches": all(same.values()), "gpu_output_matches_by_content": same, "frames_checked_per_content": int(checks[0][1].shape[0]),
            "one_thread": {"value": round(n1 / dt1, 2), "unit": "frames/s", "cores": 1, "sample": f"{n1} frames"},
            "other_mode": {"mode": "O (cv::Canny restatement, 50/150)" if a.mode == "R" else "R (reference pipeline, 10/40)", "value": round(n / dto, 2), "unit": "frames/s", "cores": cores},
            "opencv": opencv_probe(sample, cores)}

@@ -53,6 +53,7 @@ ABI_SYMBOLS = [
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
     "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals", "hc_last_run_info", "hc_pipeline_depth",
+    "hc_profile_get_front_each", "hc_hysteresis_totals",
 ]
 
 _lib = None
@@ -116,6 +117,8 @@ def load_library():
     L.hc_last_run_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.hc_pipeline_depth.argtypes = [vp, i]
     L.hc_profile_get_intervals.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(i)]
+    L.hc_profile_get_front_each.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(i)]
+    L.hc_hysteresis_totals.argtypes = [vp, C.POINTER(C.c_ulonglong), i]
     L.hc_host_alloc.restype = vp
     L.hc_host_alloc.argtypes = [sz]
     L.hc_host_free.restype = None
@@ -173,6 +176,8 @@ class Context:
 
     def set_option(self, option, value):
         _ck(self.lib.hc_set_option(self.handle, int(option), int(value)))
+        if int(option) == OPT_PER_CHANNEL:
+            self._maps_per_frame = 3 if value else 1
 
     def set_stream(self, stream_handle):
         """Run on the caller's hipStream_t (0 = the null stream, e.g. torch's default current stream)."""
@@ -202,6 +207,19 @@ class Context:
         n = C.c_int()
         _ck(self.lib.hc_profile_get_intervals(self.handle, buf, cap, C.byref(n)))
         return [buf[k] for k in range(min(cap, n.value))]
+
+    def profile_front_each(self, cap=4096):
+        """The front kernels' time (ms) of every profiled HYSTER run since the last reset, in run order."""
+        buf = (C.c_float * cap)()
+        n = C.c_int()
+        _ck(self.lib.hc_profile_get_front_each(self.handle, buf, cap, C.byref(n)))
+        return [buf[k] for k in range(min(cap, n.value))]
+
+    def hysteresis_totals(self, reset=False):
+        """(runs, runs continued from the host, launches with work, launches queued) since creation / the last reset."""
+        t = (C.c_ulonglong * 4)()
+        _ck(self.lib.hc_hysteresis_totals(self.handle, t, int(bool(reset))))
+        return tuple(int(v) for v in t)
 
     def profile_get_front(self):
         """([k_blur_ms_sum, k_nms_ms_sum], nruns) of the profiled runs that took the split front path; call before
@@ -278,7 +296,7 @@ class Context:
         """upload -> run -> download convenience."""
         n = self.upload(frames)
         self.run(final_stage, n)
-        return self.download(n)
+        return self.download(n * getattr(self, "_maps_per_frame", 1))   # per-channel mode: three maps per input frame
 
 
 def selftest(device=0):

@@ -9,7 +9,7 @@ typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 
 // The same 25 values as compile-time constants: K * (1 / 159.0f), both roundings in binary32 (constant
-// folding is IEEE round-to-nearest).  upload_gauss_coeffs() refuses a host table that differs.
+// folding is IEEE round-to-nearest).  check_gauss_coeffs() refuses a host table that differs.
 struct GaussLiterals {
   float v[25];
   constexpr GaussLiterals() : v{}

@@ -46,7 +46,10 @@ constexpr int F8_RING = F8_SUB + 4;                // rows kept in each LDS ring
 constexpr int F8_FQ = 128;                         // flagged-pixel queue entries per window (expected fill ~20); [F8_FQ] is a dump slot
 constexpr int F8_NQ = 512;                         // NMS queue (ids), circular; [F8_NQ] is a dump slot
 constexpr int F8_ROW_BYTES = 64 * 8;
-constexpr int F8_WAVE_BYTES = 2 * F8_RING * F8_ROW_BYTES + (F8_FQ + 4) * 4 + (F8_NQ + 4) * 4;  // 12,832 B: 3 workgroups of 4 waves per CU
+#ifndef F8_LDS_PAD
+#define F8_LDS_PAD 0  // experiments: extra LDS per wave (occupancy studies)
+#endif
+constexpr int F8_WAVE_BYTES = 2 * F8_RING * F8_ROW_BYTES + (F8_FQ + 4) * 4 + (F8_NQ + 4) * 4 + F8_LDS_PAD;  // 12,832 B: 3 workgroups of 4 waves per CU
 
 int front8_run_rows(int windows) { return F8_SUB * windows - 4; }
 int front8_strips(int W) { return (W + F8_STRIP_W - 1) / F8_STRIP_W; }

@@ -44,6 +44,7 @@ static_assert(WL_COUNT_WORDS >= MAX_HYST_LAUNCHES + 1, "a count per launch and o
 // share the device without noticing each other.
 constexpr int NSLOT = 4;
 struct Slot {
+  bool complete = false;                       // every allocation below succeeded (alloc_slot)
   u32 *d_sbits = nullptr, *d_cbits = nullptr;  // bit planes [max_batch][H][RD]
   u32 *d_wl_list = nullptr;  // hysteresis worklists (HystParams::wl_list)
   size_t wl_cap = 0;         // tiles a run can have
@@ -59,6 +60,7 @@ struct Slot {
   hipStream_t stream = nullptr;  // stream the hysteresis of this run was queued on
   hipStream_t s_hyst = nullptr;  // this slot's hysteresis stream (pipelined mode)
   int hyst_level = 0;            // tile height level of this run's hysteresis (hc_ctx::hyst_obs index)
+  int mixed_from = 0;            // > 0: launches below it ran a workgroup per tile, launch `mixed_from` wrote the first list, the rest took lists
   uintptr_t out0 = 0, out1 = 0;  // output range of this (pipelined, still pending) run: a later run into the same memory waits for it
 };
 }  // namespace
@@ -115,7 +117,8 @@ struct hc_ctx {
   // in RunProf::mask[i] (one kernel may cover several: its time is divided equally among them, see hc_stage_time_ms)
   static constexpr int EV_RUNS = 256;
   static constexpr int EV_PER_RUN = 8;
-  struct RunProf { int nint = 0; uint8_t mask[EV_PER_RUN - 1] = { 0 }; uint8_t kind[EV_PER_RUN - 1] = { 0 }; };
+  struct RunProf { int nint = 0; bool after_gap = false; uint8_t mask[EV_PER_RUN - 1] = { 0 }; uint8_t kind[EV_PER_RUN - 1] = { 0 }; };
+  bool prof_gap = false;  // a run went untimed since the last timed one (ring full)
   enum { K_STAGE0 = 0, K_FRONT_A = 1, K_FRONT_B = 2, K_HYST = 3 };  // grey kernel / k_blur / k_nms, the fused front kernel or the tap kernels / hysteresis
   std::vector<hipEvent_t> evpool;
   std::vector<RunProf> runprof;
@@ -127,7 +130,9 @@ struct hc_ctx {
   long prof_split_runs = 0;
   long prof_runs = 0;
   std::vector<float> step_ms;     // end-of-run to end-of-run intervals of consecutive profiled runs (steady-state step time)
-  hipEvent_t prev_end = nullptr;  // last event of the previous profiled run (still valid: the ring is 256 runs deep)
+  std::vector<float> front_each;  // the front kernels' time of every profiled HYSTER run (hc_profile_get_front_each)
+  unsigned long long hyst_totals[4] = { 0, 0, 0, 0 };  // runs, continued runs, launches with work, launches queued
+  hipEvent_t prev_end = nullptr;  // last event of the previous profiled run (its ring slot is not reused before the next collect: at most EV_RUNS - 1 runs are in flight)
 };
 
 namespace {
@@ -151,9 +156,8 @@ int ensure_stage_scratch(hc_ctx *c)
   return HC_OK;
 }
 
-int alloc_slot(hc_ctx *c, Slot &s)
+int alloc_slot_parts(hc_ctx *c, Slot &s)
 {
-  if (s.d_sbits) return HC_OK;
   const size_t out_frames = (size_t)c->max_batch * (c->per_channel ? 3 : 1);
   const size_t plane_bytes = sizeof(u32) * (size_t)c->RD * c->H * out_frames;
   HIPCK(hipMalloc((void **)&s.d_sbits, plane_bytes));
@@ -186,6 +190,21 @@ void free_slot(Slot &s)
   if (s.ev_done) (void)hipEventDestroy(s.ev_done);
   if (s.s_hyst) (void)hipStreamDestroy(s.s_hyst);
   s = Slot{};
+}
+
+// A slot is either complete or empty: slots 1..3 are allocated lazily inside a run, and a run that found d_sbits set
+// but the stream or the flag words missing would memset a null pointer and queue its hysteresis on the null stream.
+int alloc_slot(hc_ctx *c, Slot &s)
+{
+  if (s.complete) return HC_OK;
+  const int rc = alloc_slot_parts(c, s);
+  if (rc != HC_OK) {
+    const std::string why = g_err;
+    free_slot(s);
+    return fail(rc, why);
+  }
+  s.complete = true;
+  return HC_OK;
 }
 
 // split mode: blur plane [frames][strip][H][256 B] (see canny_kernels.hip); every byte k_nms reads is written by k_blur
@@ -272,6 +291,8 @@ int finish_slot(hc_ctx *c, Slot &s)
   std::memcpy(c->h_stats, s.h_flags + MAX_HYST_LAUNCHES, sizeof(c->h_stats));
   c->last_work_launches = std::min(K, work + 1);
   c->last_continued = 0;
+  c->hyst_totals[0] += 1;
+  c->hyst_totals[3] += (unsigned long long)K;
   // worklist lengths of this run's launches (wide frames): the next run of the same shape sizes its grids by them
   c->wl_prev_tiles = (s.ph.npanels > 1 || s.ph.lists) ? s.ph.wl_stride : 0;
   for (int k = 0; k <= MAX_HYST_LAUNCHES; ++k) c->wl_prev[k] = s.h_flags[FLAG_WORDS + k];
@@ -287,10 +308,12 @@ int finish_slot(hc_ctx *c, Slot &s)
     c->hyst_obs[lvl] = L;
   };
   if (s.h_flags[K - 1] == 0) {
+    c->hyst_totals[2] += (unsigned long long)c->last_work_launches;
     observe();
     return HC_OK;
   }
   c->last_continued = 1;
+  c->hyst_totals[1] += 1;
   for (int round = 0; round < 1000000; ++round) {
     HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * s.ph.wl_stride), st));  // flags, worklist counts and reasons
     HystParams hp = s.ph;
@@ -299,6 +322,8 @@ int finish_slot(hc_ctx *c, Slot &s)
     hp.stats = nullptr;
     for (int k = 0; k < K; ++k) {
       hp.iter = k;
+      // the schedule the run itself used (s.ph holds the parameters of its LAST launch)
+      if (s.mixed_from > 0) hp.lists = k < s.mixed_from ? 0 : k == s.mixed_from ? 2 : 1;
       HIPCK(launch_hyst(hp, st));
     }
     HIPCK(hipMemcpyAsync(s.h_flags, s.d_flags, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS), hipMemcpyDeviceToHost, st));
@@ -307,6 +332,7 @@ int finish_slot(hc_ctx *c, Slot &s)
     if (s.h_flags[K - 1] == 0) break;
   }
   c->hyst_need_rows = std::max(c->hyst_need_rows, c->last_work_launches * tile);
+  c->hyst_totals[2] += (unsigned long long)c->last_work_launches;
   observe();
   if (s.copy_dst)
     if (int rc = copy_frames_d2d(c, st, s.copy_dst, s.copy_pitch, s.copy_fs, s.ph.out, s.ph.out_pitch, s.ph.out_frame_stride, (size_t)c->W, s.n)) return rc;
@@ -421,6 +447,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   s.pending = true;
   s.k_launches = K;
   s.ph = hp;
+  s.mixed_from = mixed_from;
   s.n = n;
   s.stream = st;
   s.copy_dst = nullptr;
@@ -474,7 +501,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   c->last_out_staged = out_internal ? 1 : 0;
   c->last_front_form = -1;
 
-  const bool prof = c->profiling && c->ev_count < hc_ctx::EV_RUNS;  // ring full: this run goes untimed
+  // ring full: this run goes untimed.  One slot stays free: `prev_end` still points at the last event of the run collected
+  // last, and a 256th queued run would record over it
+  const bool prof = c->profiling && c->ev_count < hc_ctx::EV_RUNS - 1;
+  if (c->profiling && !prof) c->prof_gap = true;  // the next timed run's step interval would span this one
   hipEvent_t *ev = nullptr;
   hc_ctx::RunProf *rp = nullptr;
   if (prof) {
@@ -482,6 +512,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     ev = &c->evpool[slot_i * hc_ctx::EV_PER_RUN];
     rp = &c->runprof[slot_i];
     *rp = hc_ctx::RunProf{};
+    rp->after_gap = c->prof_gap;
+    c->prof_gap = false;
     HIPCK(hipEventRecord(ev[0], sf));
   }
   // closes the interval that began at the previous event: it covered `mask` (bit per reference stage)
@@ -945,11 +977,14 @@ int hc_sync(hc_ctx *c)
     const hc_ctx::RunProf &rp = c->runprof[(size_t)c->ev_head];
     for (float &m : c->stage_ms) m = 0;
     c->stage_ran = 0;
-    bool has_a = false;
+    bool has_a = false, has_h = false;
+    float front_t = 0;
     for (int i = 0; i < rp.nint; ++i) has_a = has_a || rp.kind[i] == hc_ctx::K_FRONT_A;
+    for (int i = 0; i < rp.nint; ++i) has_h = has_h || rp.kind[i] == hc_ctx::K_HYST;
     for (int i = 0; i < rp.nint; ++i) {
       float t = 0;
       HIPCK(hipEventElapsedTime(&t, e[i], e[i + 1]));
+      if (rp.kind[i] == hc_ctx::K_FRONT_A || rp.kind[i] == hc_ctx::K_FRONT_B) front_t += t;
       const unsigned mask = rp.mask[i];
       const int nst = __builtin_popcount(mask);
       for (int st = 0; st < 6; ++st)
@@ -961,8 +996,9 @@ int hc_sync(hc_ctx *c)
       else if (k == hc_ctx::K_FRONT_B && has_a) c->prof_split_sum[1] += t;
     }
     if (has_a) c->prof_split_runs++;
+    if (has_h && c->front_each.size() < 65536) c->front_each.push_back(front_t);
     if (rp.nint > 0) {
-      if (c->prev_end && c->step_ms.size() < 65536) {
+      if (c->prev_end && !rp.after_gap && c->step_ms.size() < 65536) {
         float dt = 0;
         if (hipEventElapsedTime(&dt, c->prev_end, e[rp.nint]) == hipSuccess) c->step_ms.push_back(dt);
       }
@@ -1002,6 +1038,7 @@ int hc_profile_get(hc_ctx *c, double sum_ms[3], long *nruns, int reset)
   if (nruns) *nruns = c->prof_runs;
   if (reset) {
     c->step_ms.clear(); c->prev_end = nullptr;
+    c->front_each.clear();
     c->prof_sum[0] = c->prof_sum[1] = c->prof_sum[2] = 0; c->prof_runs = 0;
     c->prof_split_sum[0] = c->prof_split_sum[1] = 0; c->prof_split_runs = 0;
   }
@@ -1024,6 +1061,16 @@ int hc_profile_get_intervals(hc_ctx *c, float *ms, int cap, int *n)
   const int m = (int)std::min<size_t>(c->step_ms.size(), (size_t)std::max(cap, 0));
   for (int i = 0; i < m; ++i) ms[i] = c->step_ms[(size_t)i];
   *n = (int)c->step_ms.size();
+  return HC_OK;
+}
+
+int hc_profile_get_front_each(hc_ctx *c, float *ms, int cap, int *n)
+{
+  if (!c || !n || (cap > 0 && !ms)) return fail(HC_E_ARG, "hc_profile_get_front_each: bad argument");
+  if (int rc = hc_sync(c)) return rc;
+  const int m = (int)std::min<size_t>(c->front_each.size(), (size_t)std::max(cap, 0));
+  for (int i = 0; i < m; ++i) ms[i] = c->front_each[(size_t)i];
+  *n = (int)c->front_each.size();
   return HC_OK;
 }
 
@@ -1116,6 +1163,15 @@ int hc_last_hysteresis_info(hc_ctx *c, int *launches_with_work, int *continued)
   if (int rc = finish_all(c)) return rc;
   if (launches_with_work) *launches_with_work = c->last_work_launches;
   if (continued) *continued = c->last_continued;
+  return HC_OK;
+}
+
+int hc_hysteresis_totals(hc_ctx *c, unsigned long long totals[4], int reset)
+{
+  if (!c || !totals) return fail(HC_E_ARG, "null argument");
+  if (int rc = finish_all(c)) return rc;
+  for (int i = 0; i < 4; ++i) totals[i] = c->hyst_totals[i];
+  if (reset) for (int i = 0; i < 4; ++i) c->hyst_totals[i] = 0;
   return HC_OK;
 }
 

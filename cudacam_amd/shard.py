@@ -76,7 +76,11 @@ def run_on_devices(frames, devices, low=10, high=40, mode=0, batch=None, options
     n, h, w = frames.shape[:3]
     ch = 1 if frames.ndim == 3 else frames.shape[3]
     world = len(devices)
-    out = np.empty((n, h, w), np.uint8)
+    # per-channel mode (BASELINE configs[4]) returns three edge maps per input frame: frame f's maps are out[3f .. 3f+2]
+    per_frame = 3 if any(opt == api.OPT_PER_CHANNEL and val for opt, val in options) else 1
+    if per_frame == 3 and ch != 3:
+        raise ValueError("OPT_PER_CHANNEL needs 3-channel frames")
+    out = np.empty((n * per_frame, h, w), np.uint8)
     errors = []
 
     def work(rank):
@@ -91,7 +95,7 @@ def run_on_devices(frames, devices, low=10, high=40, mode=0, batch=None, options
                     ctx.set_option(opt, val)
                 for s in range(a, b, step):
                     e = min(b, s + step)
-                    out[s:e] = ctx.process(frames[s:e])
+                    out[s * per_frame:e * per_frame] = ctx.process(frames[s:e])
         except Exception as exc:   # surfaced on the calling thread
             errors.append(exc)
 

@@ -67,7 +67,13 @@ int hc_run(hc_ctx *ctx, int final_stage, int nframes);
 
 /* The same on caller-owned device memory (no upload/download): `d_in` holds nframes frames of
  * width*channels bytes per row, `d_out` receives nframes tight-or-pitched u8 images.  Pointers,
- * pitches and frame strides must be multiples of 4 bytes.  Asynchronous on the context stream. */
+ * pitches and frame strides must be multiples of 4 bytes (others are staged through internal buffers, see
+ * hc_last_run_info).  Asynchronous on the context stream.
+ * Readable extent: the fast kernels load whole pixel groups, so EVERY row -- the last row of the last frame
+ * included -- must be readable for min(in_pitch, round_up(width, 8) * channels) bytes from its first byte: a
+ * caller whose rows are padded to whole 8-pixel groups (in_pitch >= round_up(width, 8) * channels) must own that
+ * padding after the last row too, i.e. allocate height * in_pitch bytes per frame.  No row is ever read beyond
+ * its pitch. */
 int hc_run_device(hc_ctx *ctx, const void *d_in, size_t in_pitch, size_t in_frame_stride, void *d_out, size_t out_pitch,
                   size_t out_frame_stride, int nframes, int final_stage);
 
@@ -117,12 +123,22 @@ int hc_profile_get_front(hc_ctx *ctx, double sum_ms[2], long *nruns);
  * this -- not a run's own start-to-end time -- is what a frame stream sees.  Writes up to `cap` values, *n = how many exist. */
 int hc_profile_get_intervals(hc_ctx *ctx, float *ms, int cap, int *n);
 
+/* The front kernels' own time (ms) of every profiled HYSTER run since the last reset, in run order: what bench.py needs
+ * to attribute kernel time to the content of each step when the batches of a stream differ.  Writes up to `cap` values,
+ * *n = how many exist. */
+int hc_profile_get_front_each(hc_ctx *ctx, float *ms, int cap, int *n);
+
 /* Internal device buffers (input frames, output images) and their pitch / frame stride. */
 int hc_device_ptrs(hc_ctx *ctx, void **d_in, void **d_out, size_t *in_pitch, size_t *out_pitch, size_t *in_frame_stride,
                    size_t *out_frame_stride);
 
 /* Number of hysteresis launches that did work in the last run, and whether the continuation ran. */
 int hc_last_hysteresis_info(hc_ctx *ctx, int *launches_with_work, int *continued);
+
+/* The same, summed over every run completed since the context was created (or since the last call with reset != 0):
+ * totals[0] = runs, totals[1] = runs that needed the host-side continuation (each one a stall of a pipelined stream),
+ * totals[2] = hysteresis launches that found work, totals[3] = hysteresis launches queued.  Completes pending runs. */
+int hc_hysteresis_totals(hc_ctx *ctx, unsigned long long totals[4], int reset);
 
 /* What the last hc_run / hc_run_device did with the caller's buffers -- no silent cliffs: *input_staged / *output_staged are
  * 1 when the frames went through the context's internal pitched buffers (an extra device-to-device copy each: pointer,

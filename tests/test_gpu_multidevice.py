@@ -46,3 +46,18 @@ def test_three_channel_blocks(oracle):
     many = shard.run_on_devices(frames, [0, 0], batch=2)
     assert np.array_equal(single, many)
     assert np.array_equal(single[3], oracle.canny_r(frames[3], 10, 40))
+
+
+def test_per_channel_blocks(oracle):
+    """OPT_PER_CHANNEL returns three maps per input frame -- the dispatcher sizes its result for that (frame
+    f's maps are rows 3f .. 3f+2) and refuses the option on one-channel frames."""
+    rng = np.random.default_rng(4)
+    frames = rng.integers(0, 256, (5, 96, 336, 3), dtype=np.uint8)
+    single = shard.run_on_devices(frames, [0], options=[(api.OPT_PER_CHANNEL, 1)])
+    many = shard.run_on_devices(frames, [0, 0], batch=2, options=[(api.OPT_PER_CHANNEL, 1)])
+    assert single.shape == (15, 96, 336)
+    assert np.array_equal(single, many)
+    for f, ch in ((0, 0), (3, 1), (4, 2)):
+        assert np.array_equal(single[3 * f + ch], oracle.canny_r(np.ascontiguousarray(frames[f, :, :, ch]), 10, 40))
+    with pytest.raises(ValueError):
+        shard.run_on_devices(frames[..., 0], [0], options=[(api.OPT_PER_CHANNEL, 1)])

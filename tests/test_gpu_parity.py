@@ -606,6 +606,32 @@ def test_pipelined_one_buffer_with_host_continuation(oracle):
             _diff(d_out.cpu().numpy()[0], want, f"one buffer, {len(order)} runs, continuation")
 
 
+@pytest.mark.parametrize("k", [3, 4])
+def test_pipelined_mixed_schedule_continuation(oracle, k):
+    """a pipelined one-panel run queues launches 0-1 with a workgroup per tile, launch 2 writes the first
+    worklist and the rest take lists.  With only 3 or 4 launches queued on a serpentine frame the host-side continuation
+    is certain, and it must replay THAT schedule (Slot::mixed_from), not the parameters of the run's last launch."""
+    import torch
+    w, h = 1000, 1100
+    serp = synth.serpentine(w, h)
+    nat = synth.natural(w, h, 78)
+    frames = np.stack([serp, nat])
+    want = oracle.canny_r_batch(frames, 10, 40, threads=4)
+    d_in = torch.from_numpy(frames).cuda()
+    d_out = [torch.zeros_like(d_in) for _ in range(2)]
+    with api.Context(w, h, 1, 2) as ctx:
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        ctx.set_tuning(0, k)
+        for r in range(3):
+            ctx.run_device(d_in.data_ptr(), w, w * h, d_out[r % 2].data_ptr(), w, w * h, 2)
+        ctx.sync()
+        _, continued = ctx.hysteresis_info()
+        assert continued == 1
+        for o in d_out:
+            for f in range(2):
+                _diff(o.cpu().numpy()[f], want[f], f"mixed schedule, {k} launches queued, frame {f}")
+
+
 def test_last_run_info_reports_form_and_staging(oracle):
     """Aligned caller buffers are used in place by k_front8; a row that does not hold whole 8-pixel groups falls back to
     k_blur + k_nms (and says so); mode O reports k_front8o (3), or the 4-px k_front_o (-1) when asked for a 4-px form."""
