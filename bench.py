@@ -32,7 +32,7 @@ HBM_MEASURED_COPY_GBPS = 6290.0
 
 
 # hc_last_run_info's front form -> (config name, kernel name)
-FORM_NAME = {2: ("front8", "k_front8"), 1: ("split", "k_blur+k_nms"), 0: ("fused4", "k_front"), 3: ("k_front8o", "k_front8o"), -1: ("k_front_o", "k_front_o")}
+FORM_NAME = {2: ("front8", "k_front8"), 4: ("front8-half", "k_front8 (half-strip form)"), 1: ("split", "k_blur+k_nms"), 0: ("fused4", "k_front"), 3: ("k_front8o", "k_front8o"), -1: ("k_front_o", "k_front_o")}
 
 
 def parse():
@@ -259,7 +259,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
                            "launches_with_work_mean": round(h_work / max(h_runs, 1), 2), "launches_queued_mean": round(h_queued / max(h_runs, 1), 2)},
             "by_content": _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch),
             # the caller's buffers were used in place (no hidden staging copies) and the front path that actually ran
-            "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form)},
+            "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {4: "k_front8 (half-strip form)", 3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form)},
         }
         # HBM bytes per launch of the front kernels from the committed PMC passes (separate rocprofv3 runs of this
         # command, tools/collect_profiles.sh); only quoted when that profile was taken on this very configuration

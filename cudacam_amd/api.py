@@ -45,6 +45,8 @@ OPT_PER_CHANNEL = 3
 OPT_FRONT_SPLIT = 4
 OPT_L2_GRADIENT = 5
 OPT_DEBUG_TAPS = 6
+OPT_FRONT_HALF = 7
+OPT_FRONT_DENSE = 8
 TAP_BLUR, TAP_THRESH = 1, 2
 
 # every symbol include/hipcanny.h declares

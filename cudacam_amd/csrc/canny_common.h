@@ -47,8 +47,16 @@ struct FrontParams {
   uint8_t *prov_out; u32 prov_pitch; size_t prov_fs;
   // diagnostics (HC_OPT_DEBUG_TAPS): the fused kernel also stores its (fixed-up) blur rows here, plain [frame][H][pitch]
   uint8_t *dbg_blur; u32 dbg_pitch; size_t dbg_fs;
-  const uint8_t *zeros;  // k_front8: >= 3 * 8192 + 32 bytes of zeros (what rows above / below the image read as)
-  uint8_t *dump;   // k_front8: >= 16 KiB that may be overwritten with anything (where the branch-free row code stores rows that are not its own)
+  const uint8_t *zeros;  // k_front8: >= 3 * 8192 + 32 bytes of zeros (what rows above / below the image read as); HALF form: + in_frame_stride
+  // k_front8: memory that may be overwritten with anything -- where the branch-free row code stores rows that are not its
+  // own: STRONG plane bytes (dump), CANDIDATE plane bytes (dump_c), provisional map (dump_p).  Plain form: 2 KiB, 2 KiB,
+  // W + 8 bytes.  HALF form: each + the byte offset of half-wave B's frame (3 * H * RD * 4 / 3 * prov_fs at most).
+  uint8_t *dump, *dump_c, *dump_p;
+  int half;        // k_front8: HALF form (two 240-column half-strips per wave, narrow frames); nstrips is unused then
+  int nhalf;       // HALF form: half-strips per frame = ceil(W / 240); total_items = ceil(in_frames * nhalf / 2) * nchunks (* 3 per-channel)
+  // k_front8: a window that follows one with more than dense_enter half-lanes above the low threshold takes the dense path
+  // (wave-wide NMS in registers), and the windows after it while they count more than dense_leave (0x7FFFFFFF: never)
+  int dense_enter, dense_leave;
   u32 wrap_limit;  // S >= wrap_limit: gradient >= 256, the wrap bands apply (0xFFFFFFFF: saturating variant)
 };
 
@@ -98,6 +106,7 @@ hipError_t launch_front8(const FrontParams &p, hipStream_t s);
 hipError_t launch_front8o(const FrontParams &p, hipStream_t s);  // Mode O on the same skeleton (one-channel sources)
 int front8_run_rows(int windows);
 int front8_strips(int W);
+int front8_half_strips(int W);
 hipError_t launch_blur(const FrontParams &p, hipStream_t s);
 hipError_t launch_nms(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);

@@ -40,6 +40,7 @@
 namespace hc {
 
 constexpr int F8_STRIP_W = 62 * 8;                 // 496 output columns per wave
+constexpr int F8_HSTRIP_W = 30 * 8;                // HALF form: 240 output columns per half-wave (lanes 0 / 31 and 32 / 63 are its halo lanes)
 constexpr int F8_HALO = 8;                         // one lane each side
 constexpr int F8_SUB = 6;                          // rows per window = lcm(2, 3) rows: the d / s register ring has period 2
 constexpr int F8_RING = F8_SUB + 4;                // rows kept in each LDS ring (masked input rows; blur rows)
@@ -53,6 +54,7 @@ constexpr int F8_WAVE_BYTES = 2 * F8_RING * F8_ROW_BYTES + (F8_FQ + 4) * 4 + (F8
 
 int front8_run_rows(int windows) { return F8_SUB * windows - 4; }
 int front8_strips(int W) { return (W + F8_STRIP_W - 1) / F8_STRIP_W; }
+int front8_half_strips(int W) { return (W + F8_HSTRIP_W - 1) / F8_HSTRIP_W; }
 size_t front8_lds_bytes() { return (size_t)4 * F8_WAVE_BYTES; }
 
 typedef __attribute__((address_space(3))) u32 lds_u32;
@@ -85,7 +87,13 @@ static __device__ __forceinline__ u32 f8_chain(const unsigned char *ring, u32 sl
 
 // IN: 0 mono plane, 1 interleaved BGR -> grey (stage 0 fused into the load), 2 one channel of interleaved 3-channel data
 // PROV: also write the provisional 0/255 map (strong pixels) that the hysteresis then only patches (pipelined mode)
-template <int IN, bool PROV>
+// HALF: narrow frames.  A wave of the plain form spans 496 columns whether they exist or not -- 640 columns cost two waves, 62.5 %
+// of their lanes.  In the HALF form a wave is TWO independent half-waves of 30 own lanes + 2 halo lanes each (240 columns):
+// the units (frame, half-strip) of one run of rows are dealt to the half-waves in pairs -- 640 columns = 3 units = 1.5 waves --
+// so the two halves of a wave may belong to different strips and to different (adjacent) frames.  Rows, and with them all
+// control flow, stay wave-uniform; what depends on the strip or the frame becomes a per-lane offset.  The DPP wave shifts
+// need no fence between lanes 31 and 32: both are halo lanes, whose far neighbour is never consumed.
+template <int IN, bool PROV, bool HALF>
 __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -106,13 +114,29 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   int ch = 0;
   if (IN == 2) { ch = item % 3; item /= 3; }
   const int chunk = item % p.nchunks;
-  const int strip = (item / p.nchunks) % p.nstrips;
-  const int in_frame = item / (p.nchunks * p.nstrips);
-  const int frame = IN == 2 ? in_frame * 3 + ch : in_frame;  // output frame = bit-plane index
   const int W = p.W, H = p.H;
+  // plain form: (strip, frame) of the wave.  HALF form: those of half-wave A (lanes 0..31); half-wave B (lanes 32..63)
+  // takes the next unit in (frame, half-strip) order -- sB / dframe -- or, beyond the last unit, a strip right of the image
+  int strip, in_frame, sB = 0, dframe = 0;
+  if constexpr (HALF) {
+    const int uA = 2 * (item / p.nchunks), uB = uA + 1;
+    in_frame = uA / p.nhalf; strip = uA % p.nhalf;
+    if (uB < p.nhalf * (IN == 2 ? p.nframes / 3 : p.nframes)) { sB = uB % p.nhalf; dframe = uB / p.nhalf - in_frame; }
+    else { sB = p.nhalf; dframe = 0; }
+  } else {
+    strip = (item / p.nchunks) % p.nstrips;
+    in_frame = item / (p.nchunks * p.nstrips);
+  }
+  const int frame = IN == 2 ? in_frame * 3 + ch : in_frame;  // output frame = bit-plane index (of half-wave A)
   const int r0 = chunk * p.run_rows;  // output rows [r0, rend)
   const int rend = min(r0 + p.run_rows, H);
-  const int c0 = strip * F8_STRIP_W - F8_HALO + lane * 8;
+  const bool hB = HALF && lane >= 32;        // this lane belongs to half-wave B
+  const int ll = HALF ? (lane & 31) : lane;  // lane within its (half-)wave
+  const int c0 = HALF ? (hB ? sB : strip) * F8_HSTRIP_W - F8_HALO + ll * 8 : strip * F8_STRIP_W - F8_HALO + lane * 8;
+  // per-lane offsets of half-wave B's frame (0 in the plain form): launch_front8 checks that they fit 32 bits
+  const u32 d_in = hB ? (u32)dframe * (u32)p.in_frame_stride : 0u;
+  const u32 d_plane = hB ? (u32)(IN == 2 ? 3 * dframe : dframe) * (u32)H * (u32)p.RD * 4u : 0u;
+  const u32 d_prov = (PROV && hB) ? (u32)(IN == 2 ? 3 * dframe : dframe) * (u32)p.prov_fs : 0u;
 
   // per-lane column validity: byte masks of the two packed u8 dwords
   u32 cmask[2] = { 0, 0 };
@@ -121,14 +145,17 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     const bool in = (c0 + k >= 0) && (c0 + k < W);
     cmask[k >> 2] |= in ? (0xFFu << (8 * (k & 3))) : 0u;
   }
-  const bool own_lane = lane >= 1 && lane <= 62;
+  constexpr int LAST = HALF ? 31 : 63;  // the right halo lane of a (half-)wave
+  const bool own_lane = ll >= 1 && ll <= LAST - 1;
   // "undecidable" flag positions this lane answers for: its own 8 pixels; in the halo lanes the two next to the strip
-  const u32 hmask0 = cmask[0] & (own_lane ? 0x80808080u : lane == 63 ? 0x00008080u : 0u);
-  const u32 hmask1 = cmask[1] & (own_lane ? 0x80808080u : lane == 0 ? 0x80800000u : 0u);
+  const u32 hmask0 = cmask[0] & (own_lane ? 0x80808080u : ll == LAST ? 0x00008080u : 0u);
+  const u32 hmask1 = cmask[1] & (own_lane ? 0x80808080u : ll == 0 ? 0x80800000u : 0u);
   const bool col_any = (cmask[0] | cmask[1]) != 0;
   const uint8_t *frame_base = p.in + (size_t)in_frame * p.in_frame_stride;
   const u32 in_pitch32 = (u32)p.in_pitch;  // launch_front8 checks H * pitch < 2^32 and pitch >= (IN ? 3 : 1) * round_up(W, 8)
-  const u32 ld_safe = col_any ? (u32)((IN ? 3 : 1) * c0) : 0u;  // lanes without an image column read the row's first bytes (masked)
+  // lanes without an image column read the row's first bytes (masked).  (HALF: rows outside the image are read at the same
+  // offset from the page of zeros, which launch_front8 requires to be a frame stride longer than in the plain form.)
+  const u32 ld_safe = (col_any ? (u32)((IN ? 3 : 1) * c0) : 0u) + d_in;
   const u32 selA = ch == 0 ? 0x0c060300u : ch == 1 ? 0x0c070401u : 0x0c0c0502u;
   const u32 selB = ch == 0 ? 0x05020100u : ch == 1 ? 0x06020100u : 0x07040100u;
 
@@ -202,8 +229,8 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
       a1[j] = h0;
     }
   };
-  u32 fifteen = 15u;
-  asm volatile("" : "+v"(fifteen));  // the SDWA shift takes its count from a VGPR
+  u32 magic159 = 105518u;  // ceil(2^24 / 159)
+  asm volatile("" : "+s"(magic159));  // (an SGPR operand of the SDWA multiplies, not a literal)
   int qn = 0;                        // flagged-pixel queue fill of the current window (wave-uniform)
   const u32 lane_id2 = (u32)lane << 2;
   // input row jr (its masked pixels in x) goes to ring slot `islot` and completes blur row jr - 2, which goes to blur-ring
@@ -215,20 +242,23 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     if constexpr (decltype(warm)::value) return;
     const int rb = jr - 2;
     const u32 rowm = (u32)rb < (u32)H ? 0xFFFFFFFFu : 0u;  // blur rows outside the image are zero padding for the Sobel stage
-    // n = floor(S/159) = (S*52759) >> 23, exact for S <= 40545; S % 159 == 0 <=> bits 15..22 of the product are all zero:
-    // after >> 15 one 16-bit half holds the quotient byte above a "fraction byte" whose zero test flags the pixel
-    const u16x2 mlo = { 52759, 0 }, mhi = { 0, 52759 };
-    u32 t[4];
+    // n = floor(S / 159) = (S * 105518) >> 24, exact for S <= 40545 (the product stays below 2^32), and S % 159 == 0 <=> bits
+    // 16..23 of the product are all zero: byte 3 of the product IS the blur value, byte 2 the "fraction byte" whose zero
+    // test flags the pixel -- one 24-bit multiply per pixel (SDWA picks the half of the packed sum) and byte permutes,
+    // no shifts (round 2: two v_dot2 per pair by 52759, >> 15, an SDWA shift to merge the halves)
+    u32 P[8];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      t[j] = __builtin_amdgcn_udot2(U(Sp[j]), mlo, 0u, false) >> 15;
-      const u32 ph = __builtin_amdgcn_udot2(U(Sp[j]), mhi, 0u, false);
-      asm("v_lshrrev_b32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD" : "+v"(t[j]) : "v"(fifteen), "v"(ph));
+      asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(P[2 * j]) : "v"(Sp[j]), "s"(magic159));
+      asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(P[2 * j + 1]) : "v"(Sp[j]), "s"(magic159));
     }
-    const u32 qsel = (u32)rb < (u32)H ? 0x07050301u : 0x0c0c0c0cu;  // wave-uniform selector: a blur row outside the image is all zero
-    const u32 bl0 = __builtin_amdgcn_perm(t[1], t[0], qsel) & cmask[0];  // bytes f q f q | f q f q -> the four quotients
-    const u32 bl1 = __builtin_amdgcn_perm(t[3], t[2], qsel) & cmask[1];
-    const u32 fz0 = __builtin_amdgcn_perm(t[1], t[0], 0x06040200u), fz1 = __builtin_amdgcn_perm(t[3], t[2], 0x06040200u);
+    // (q, q, f, f) of two pixels, then the four quotients / fractions of a dword of pixels
+    const u32 X01 = __builtin_amdgcn_perm(P[1], P[0], 0x06020703u), X23 = __builtin_amdgcn_perm(P[3], P[2], 0x06020703u);
+    const u32 X45 = __builtin_amdgcn_perm(P[5], P[4], 0x06020703u), X67 = __builtin_amdgcn_perm(P[7], P[6], 0x06020703u);
+    const u32 qsel = (u32)rb < (u32)H ? 0x05040100u : 0x0c0c0c0cu;  // wave-uniform selector: a blur row outside the image is all zero
+    const u32 bl0 = __builtin_amdgcn_perm(X23, X01, qsel) & cmask[0];
+    const u32 bl1 = __builtin_amdgcn_perm(X67, X45, qsel) & cmask[1];
+    const u32 fz0 = __builtin_amdgcn_perm(X23, X01, 0x07060302u), fz1 = __builtin_amdgcn_perm(X67, X45, 0x07060302u);
     // zero-byte detector (a byte equal to 1 above a zero byte may be flagged too: harmless)
     const u32 hz0 = (fz0 - 0x01010101u) & ~fz0 & hmask0, hz1 = (fz1 - 0x01010101u) & ~fz1 & hmask1;
     const u32 hz = (hz0 >> 7) | (hz1 >> 6);
@@ -255,14 +285,16 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   // the lane's 8 columns are byte c0 / 8 of a plane row.  Lanes that own no byte (halo lanes, lanes right of the image)
   // store their zero onto lane 1's byte instead: no exec masking around the stores
   const bool st_lane = own_lane && col_any;
-  const u32 st_off = st_lane ? (u32)(strip * 62 + lane - 1) : (u32)(strip * 62);
-  const u32 prov_voff = st_lane ? (u32)c0 : (u32)(strip * F8_STRIP_W);
+  // (byte c0 / 8 of the plane row; the others store onto the byte of the wave's lane 1, which always owns columns)
+  const u32 st_off = HALF ? (st_lane ? (u32)(c0 >> 3) + d_plane : (u32)(strip * 30)) : st_lane ? (u32)(strip * 62 + lane - 1) : (u32)(strip * 62);
+  const u32 prov_voff = HALF ? (st_lane ? (u32)c0 + d_prov : (u32)(strip * F8_HSTRIP_W)) : st_lane ? (u32)c0 : (u32)(strip * F8_STRIP_W);
   const u32 a_lo0 = p.a_lo[0], a_hi0 = p.a_hi[0], wrap_limit = p.wrap_limit;
   // own lanes whose half h has a column inside the image (lanes 0 and 63 only carry halo columns)
   const u64 lanes0 = uniform64(__ballot(own_lane && cmask[0] != 0)), lanes1 = uniform64(__ballot(own_lane && cmask[1] != 0));
   uint8_t *prov_frame = PROV ? p.prov_out + (size_t)frame * p.prov_fs : nullptr;
 
   int qhead = 0, qcount = 0;  // NMS queue (circular, F8_NQ ids): wave-uniform
+  int wq = 0;                 // half-lanes that passed the low-threshold test in the window being processed (wave-uniform)
   // blur row k (its 8 bytes per lane in b0, b1) arrives -> Sobel row k-1 -> the row's candidates are queued.  No branch.
   auto step = [&](auto uc, int k, u32 b0, u32 b1) {
     constexpr int u = decltype(uc)::value;
@@ -302,13 +334,13 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
       // (typed as global pointers: from the opaque select the compiler would otherwise build 64-bit flat addresses per lane)
       typedef __attribute__((address_space(1))) uint8_t gmem_u8;
       typedef __attribute__((address_space(1))) g_u32x2 gmem_u32x2;
-      gmem_u8 *sp = (gmem_u8 *)uniform_sel(valid, splane + (u32)c * plane_pitch, p.dump), *cp = (gmem_u8 *)uniform_sel(valid, cplane + (u32)c * plane_pitch, p.dump + 2048);
+      gmem_u8 *sp = (gmem_u8 *)uniform_sel(valid, splane + (u32)c * plane_pitch, p.dump), *cp = (gmem_u8 *)uniform_sel(valid, cplane + (u32)c * plane_pitch, p.dump_c);
       u32 so = st_off;
       asm volatile("" : "+v"(so));
       sp[so] = 0;
       cp[so] = 0;
       if constexpr (PROV) {
-        gmem_u8 *pp = (gmem_u8 *)uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump + 4096);
+        gmem_u8 *pp = (gmem_u8 *)uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump_p);
         u32 o = prov_voff;
         asm volatile("" : "+v"(o));
         *reinterpret_cast<gmem_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
@@ -326,6 +358,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n0) : "s"(mh0) : "scc");
     asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n1) : "s"(mh1) : "scc");
     qcount += (int)(n0 + n1);
+    wq += (int)(n0 + n1);
   };
 
   // One dense NMS pass: up to 64 queued half-lanes, an entry per lane.  sbase: blur-ring slot of blur row bw0 - 4.
@@ -340,7 +373,9 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     const u32 id = nq[(u32)(qhead + lane) & (u32)(F8_NQ - 1)];  // bits 0..5 lane, bit 6 half, bit 7 "the next entry is my lane's other half", bits 8.. row
     const u32 sl = live ? (id & 63u) : 1u, half = (id >> 6) & 1u;
     const int row = live ? (int)(id >> 8) : bw0;
-    const int col0 = strip * F8_STRIP_W - F8_HALO + 8 * (int)sl + 4 * (int)half;  // column of the half's pixel 0
+    const bool eB = HALF && sl >= 32u;  // HALF form: the entry belongs to half-wave B (its strip, its frame)
+    const int col0 = HALF ? (eB ? sB : strip) * F8_HSTRIP_W - F8_HALO + 8 * (int)(sl & 31u) + 4 * (int)half
+                          : strip * F8_STRIP_W - F8_HALO + 8 * (int)sl + 4 * (int)half;  // column of the half's pixel 0
     // blur rows row-2 .. row+2, columns col0-4 .. col0+7 (three aligned dwords; -2 .. +5 are used)
     const u32 rel = (u32)(row - (bw0 - 2));  // 0..5: the window's output rows are bw0-2 .. bw0+3
     const u32 lo = sl * 8u + half * 4u - 4u;
@@ -430,14 +465,126 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     const bool second = lane > 0 && (prev_id & 0x80u) != 0;  // a half that follows its lane's half 0 is stored by that entry
     const u32 w = first ? (nib | (nxt << 4)) : (nib << (4 * half));
     if (live && !second) {
-      const u32 o = (u32)row * plane_pitch + (u32)(strip * 62) + sl - 1u;
+      const u32 o = HALF ? (u32)row * plane_pitch + (u32)((col0 - 4 * (int)half) >> 3) + (eB ? (u32)(IN == 2 ? 3 * dframe : dframe) * (u32)H * plane_pitch : 0u)
+                         : (u32)row * plane_pitch + (u32)(strip * 62) + sl - 1u;
       splane[o] = (uint8_t)w;
       cplane[o] = (uint8_t)(w >> 8);
     }
     if (PROV && live)
-      *reinterpret_cast<u32 *>(prov_frame + (u32)row * p.prov_pitch + (u32)col0) = nibble_to_bytes(nib & 0xFu);
+      *reinterpret_cast<u32 *>(prov_frame + (u32)row * p.prov_pitch + (u32)col0 + ((HALF && eB) ? (u32)(IN == 2 ? 3 * dframe : dframe) * (u32)p.prov_fs : 0u)) = nibble_to_bytes(nib & 0xFu);
     qhead = (qhead + nent) & (F8_NQ - 1);
     qcount -= nent;
+  };
+
+
+  // ---- dense windows: wave-wide non-maximum suppression in registers ---------------------------------------------------
+  // The queue + batch scheme above wins while few half-lanes pass the low threshold (6-7 % on camera-like frames: 27 + 41
+  // instructions per row for the test and the queue, ~230 per batch of 64).  On dense content -- noise: every half-lane
+  // passes, two batches per row -- it costs 2.6 x a natural frame (round 2: 132 k frames/s against 225 k with round 1's
+  // wave-wide k_nms).  A window that follows one with more than p.dense_enter queued half-lanes is therefore processed
+  // whole, by every lane for its own 8 pixels: the 10 blur rows of the ring -> d / s -> the Sobel sums and the exact S2
+  // of 8 rows (two more than it outputs: no state is carried from the window before) -> thresholds, direction bins and
+  // the non-strict NMS of the 6 output rows against the rows above / below in registers and the neighbours' columns by
+  // DPP -> one byte of each plane and 8 bytes of provisional map per lane and row, stored once (no zero-stores, no queue,
+  // no LDS beyond the 10 row reads).  ~260 instructions per row whatever the content.  The arithmetic is the batch's.
+  bool dense = p.dense_enter < 0;  // this window takes the dense path (HC_OPT_FRONT_DENSE = 1: every window, tests)
+  auto dense_window = [&](int bw0, u32 sbase) {
+    // pixels outside the image have zero gradients (cannyEdgeD.cu:142-149, 222-229): half-word masks of the lane's aligned pairs
+    const u32 pm[4] = { __builtin_amdgcn_perm(0u, cmask[0], 0x01010000u), __builtin_amdgcn_perm(0u, cmask[0], 0x03030202u),
+                        __builtin_amdgcn_perm(0u, cmask[1], 0x01010000u), __builtin_amdgcn_perm(0u, cmask[1], 0x03030202u) };
+    u32 dP[2][4], sP[2][4];              // d / s of the two previous blur rows
+    u32 SU[10], SC[10], SN[10];          // S2 of three Sobel rows: [0] = pixel -1 (the lane below), [1 + q] = pixel q, [9] = pixel 8
+    u32 Xc[4], Yc[4], Xn[4], Yn[4];      // the Sobel sums of the centre row / the newest row (packed pairs)
+#pragma unroll
+    for (int k = 0; k < 10; ++k) SU[k] = SC[k] = SN[k] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dP[0][j] = dP[1][j] = sP[0][j] = sP[1][j] = Xc[j] = Yc[j] = Xn[j] = Yn[j] = 0;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {  // blur row bw0 - 4 + i
+      u32 slot = sbase + (u32)i;
+      slot = slot >= (u32)F8_RING ? slot - (u32)F8_RING : slot;
+      const u32x2 b = *reinterpret_cast<const u32x2 *>(bring + slot * (u32)F8_ROW_BYTES + lane * 8);
+      const u32 A0 = unpack_lo(b.x), B0 = unpack_hi(b.x), A1 = unpack_lo(b.y), B1 = unpack_hi(b.y);
+      const u32 Bl = from_lane_below(B1), Ar = from_lane_above(A0);
+      const u32 m1 = pair_shift(A0, Bl), p1 = pair_shift(B0, A0), p3 = pair_shift(A1, B0), p5 = pair_shift(B1, A1), p7 = pair_shift(Ar, B1);
+      const u32 Cc[4] = { A0, B0, A1, B1 };
+      const u32 Lf[4] = { m1, p1, p3, p5 }, Rt[4] = { p1, p3, p5, p7 };
+      u32 dk[4], sk[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dk[j] = R(I(Rt[j]) - I(Lf[j]));
+        sk[j] = pk_mad2(Cc[j], Lf[j] + Rt[j]);
+      }
+      if (i >= 2) {  // Sobel row bw0 - 5 + i from blur rows i - 2, i - 1, i
+        int c = bw0 - 5 + i;
+        asm volatile("" : "+s"(c));
+        const u32 rm = (u32)c < (u32)H ? 0xFFFFFFFFu : 0u;  // (wave-uniform) rows outside the image: zero gradients
+#pragma unroll
+        for (int k = 0; k < 10; ++k) { SU[k] = SC[k]; SC[k] = SN[k]; }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Xc[j] = Xn[j]; Yc[j] = Yn[j];
+          const u32 msk = pm[j] & rm;
+          const u32 X = pk_mad2(dP[(i - 1) & 1][j], R(I(dP[i & 1][j]) + I(dk[j]))) & msk;  // cannyEdgeD.cu:158-162
+          const u32 Y = R(I(sP[i & 1][j]) - I(sk[j])) & msk;                                // :163-167
+          Xn[j] = X; Yn[j] = Y;
+          SN[1 + 2 * j] = (u32)mad16<0, 0>(X, X, mul16<0, 0>(Y, Y));
+          SN[2 + 2 * j] = (u32)mad16<1, 1>(X, X, mul16<1, 1>(Y, Y));
+        }
+        SN[0] = from_lane_below(SN[8]);
+        SN[9] = from_lane_above(SN[1]);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { dP[i & 1][j] = dk[j]; sP[i & 1][j] = sk[j]; }
+      if (i == 7 || i == 8) {  // what the next window's first steps expect: d / s of blur rows bw0 + 3 and bw0 + 4
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { dr[i - 7][j] = dk[j]; sr[i - 7][j] = sk[j]; }
+      }
+      if (i >= 4) {  // NMS of output row bw0 - 6 + i: centre SC, above SU, below SN
+        int c = bw0 - 6 + i;
+        asm volatile("" : "+s"(c));  // (keeps the six rows' addresses from being computed -- and held in SGPRs -- ahead of the loop)
+        const bool valid = (u32)(c - r0) < (u32)(rend - r0);  // wave-uniform
+        const u32 g0 = max(max(SC[1], SC[2]), max(SC[3], SC[4])), g1 = max(max(SC[5], SC[6]), max(SC[7], SC[8]));
+        // the same measure as the queue path's: half-lanes with a pixel above the low threshold
+        const u64 mh0 = __ballot(g0 >= a_lo0) & (valid ? lanes0 : 0ull), mh1 = __ballot(g1 >= a_lo0) & (valid ? lanes1 : 0ull);
+        cnt += __popcll(mh0) + __popcll(mh1);
+        if (valid) {
+          const bool wraps = __ballot(max(g0, g1) >= wrap_limit) != 0;
+          u32 bitsS = 0, bitsC = 0;
+          u32 A2[4], Um[4], Vp[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { A2[j] = R(U(Xc[j]) + U(Xc[j])); Um[j] = R(I(Xc[j]) - I(Yc[j])); Vp[j] = R(U(Xc[j]) + U(Yc[j])); }
+          auto px = [&](auto qc) {
+            constexpr int q = decltype(qc)::value, j = q / 2, e = q % 2;
+            const u32 g = SC[1 + q];
+            bool cand = g >= a_lo0, strong = g >= a_hi0;
+            if (wraps) {  // u8 wrap of gradients >= 256 (cannyEdgeD.cu:267)
+              const bool w0 = g >= 262144u, w1 = g >= 1048576u;
+              cand = (cand && !w0) || (g >= p.a_lo[1] && !w1) || g >= p.a_lo[2];
+              strong = (strong && !w0) || (g >= p.a_hi[1] && !w1) || g >= p.a_hi[2];
+            }
+            // direction bins (cannyEdgeD.cu:239-264): E1 = 2x(x-y) - S2 > 0, E2 = 2x(x+y) - S2 > 0
+            const bool p1 = mul16<e, e>(A2[j], Um[j]) > (int)g, p2 = mul16<e, e>(A2[j], Vp[j]) > (int)g;
+            const u32 n0 = max(SN[1 + q], SU[1 + q]), n1 = max(SN[q], SU[2 + q]);
+            const u32 n2 = max(SC[2 + q], SC[q]), n3 = max(SU[q], SN[2 + q]);
+            const u32 mb = p1 ? (p2 ? n2 : n3) : (p2 ? n1 : n0);
+            const bool keep = mb <= g;  // non-strict on both sides, as the reference
+            bitsS |= (strong && keep) ? (1u << q) : 0u;
+            bitsC |= (cand && keep) ? (1u << q) : 0u;
+          };
+          px(std::integral_constant<int, 0>{}); px(std::integral_constant<int, 1>{}); px(std::integral_constant<int, 2>{}); px(std::integral_constant<int, 3>{});
+          px(std::integral_constant<int, 4>{}); px(std::integral_constant<int, 5>{}); px(std::integral_constant<int, 6>{}); px(std::integral_constant<int, 7>{});
+          if (st_lane) {  // (out-of-image pixels have S2 = 0: never candidates, a_lo >= 4)
+            splane[(u32)c * plane_pitch + st_off] = (uint8_t)bitsS;
+            cplane[(u32)c * plane_pitch + st_off] = (uint8_t)bitsC;
+            if constexpr (PROV)
+              *reinterpret_cast<g_u32x2 *>(prov_frame + (u32)c * p.prov_pitch + prov_voff) = u32x2{ nibble_to_bytes(bitsS & 0xFu), nibble_to_bytes(bitsS >> 4) };
+          }
+        }
+      }
+    }
+    wq = cnt;
   };
 
   // ---- the run -------------------------------------------------------------------------------------------------------
@@ -502,7 +649,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
         const u32 rel = (u32)e / (u32)F8_ROW_BYTES;
         const int row = bw0 + (int)rel;
         const u32 cb = (u32)e % (u32)F8_ROW_BYTES;
-        const int col = strip * F8_STRIP_W - F8_HALO + (int)cb;
+        const int col = HALF ? (cb >= 256u ? sB : strip) * F8_HSTRIP_W - F8_HALO + (int)(cb & 255u) : strip * F8_STRIP_W - F8_HALO + (int)cb;
         u32 es = (u32)bslot0 + rel;
         es = min(es, es - (u32)F8_RING);
         u32 s0 = (u32)islot + rel;
@@ -525,19 +672,26 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
 #pragma unroll
       for (int j = 0; j < F8_SUB; ++j) {
         const int k = bw0 - 1 + j;
-        if (k >= r0 && k < rend) *reinterpret_cast<g_u32x2 *>(p.dbg_blur + (size_t)frame * p.dbg_fs + (size_t)k * p.dbg_pitch + (u32)c0) = bq[j];
+        if (k >= r0 && k < rend) *reinterpret_cast<g_u32x2 *>(p.dbg_blur + (size_t)(frame + (hB ? (IN == 2 ? 3 * dframe : dframe) : 0)) * p.dbg_fs + (size_t)k * p.dbg_pitch + (u32)c0) = bq[j];
       }
     }
     int sb = bslot0 - 4;  // blur-ring slot of blur row bw0 - 4
     if (sb < 0) sb += F8_RING;
-    step(std::integral_constant<int, 0>{}, bw0 - 1, bq[0].x, bq[0].y);
-    step(std::integral_constant<int, 1>{}, bw0 + 0, bq[1].x, bq[1].y);
-    step(std::integral_constant<int, 2>{}, bw0 + 1, bq[2].x, bq[2].y);
-    while (qcount >= 64) nms_batch(64, bw0, (u32)sb);
-    step(std::integral_constant<int, 3>{}, bw0 + 2, bq[3].x, bq[3].y);
-    step(std::integral_constant<int, 4>{}, bw0 + 3, bq[4].x, bq[4].y);
-    step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
-    while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
+    if (dense) {
+      dense_window(bw0, (u32)sb);
+    } else {
+      wq = 0;
+      step(std::integral_constant<int, 0>{}, bw0 - 1, bq[0].x, bq[0].y);
+      step(std::integral_constant<int, 1>{}, bw0 + 0, bq[1].x, bq[1].y);
+      step(std::integral_constant<int, 2>{}, bw0 + 1, bq[2].x, bq[2].y);
+      while (qcount >= 64) nms_batch(64, bw0, (u32)sb);
+      step(std::integral_constant<int, 3>{}, bw0 + 2, bq[3].x, bq[3].y);
+      step(std::integral_constant<int, 4>{}, bw0 + 3, bq[4].x, bq[4].y);
+      step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
+      while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
+    }
+    // the next window: dense when this one queued (or, on the dense path, counted) many half-lanes; with hysteresis
+    dense = wq > (dense ? p.dense_leave : p.dense_enter);
     wave_lds_sync();  // the next window's phase 1 overwrites the oldest ring rows
     if (IN == 2) __syncthreads();  // the three channels of this run stay within a window of each other (see above)
     bslot0 = bslot0 + F8_SUB >= F8_RING ? bslot0 + F8_SUB - F8_RING : bslot0 + F8_SUB;
@@ -658,13 +812,13 @@ __global__ __launch_bounds__(256) void k_front8o(const FrontParams p)
     {
       typedef __attribute__((address_space(1))) uint8_t gmem_u8;
       typedef __attribute__((address_space(1))) g_u32x2 gmem_u32x2;
-      gmem_u8 *sp = (gmem_u8 *)uniform_sel(valid, splane + (u32)c * plane_pitch, p.dump), *cp = (gmem_u8 *)uniform_sel(valid, cplane + (u32)c * plane_pitch, p.dump + 2048);
+      gmem_u8 *sp = (gmem_u8 *)uniform_sel(valid, splane + (u32)c * plane_pitch, p.dump), *cp = (gmem_u8 *)uniform_sel(valid, cplane + (u32)c * plane_pitch, p.dump_c);
       u32 so = st_off;
       asm volatile("" : "+v"(so));
       sp[so] = 0;
       cp[so] = 0;
       if constexpr (PROV) {
-        gmem_u8 *pp = (gmem_u8 *)uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump + 4096);
+        gmem_u8 *pp = (gmem_u8 *)uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump_p);
         u32 o = prov_voff;
         asm volatile("" : "+v"(o));
         *reinterpret_cast<gmem_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
@@ -856,20 +1010,33 @@ static hipError_t launch_front8_t(const FrontParams &p, hipStream_t s)
   if (IN == 2 && p.total_items % 3 != 0) return hipErrorInvalidValue;
   const dim3 grid((unsigned)((p.total_items + WPB - 1) / WPB)), block(64 * WPB);
   const size_t lds = (size_t)WPB * F8_WAVE_BYTES;
-  if (p.prov_out) hipLaunchKernelGGL((k_front8<IN, true>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((k_front8<IN, false>), grid, block, lds, s, p);
+  if (p.half) {
+    if (p.prov_out) hipLaunchKernelGGL((k_front8<IN, true, true>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_front8<IN, false, true>), grid, block, lds, s, p);
+  } else {
+    if (p.prov_out) hipLaunchKernelGGL((k_front8<IN, true, false>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_front8<IN, false, false>), grid, block, lds, s, p);
+  }
   return hipGetLastError();
 }
 
 hipError_t launch_front8(const FrontParams &p, hipStream_t s)
 {
   const int windows = (p.run_rows + 4) / F8_SUB;
-  if (windows < 1 || p.run_rows != front8_run_rows(windows) || p.nchunks * p.run_rows < p.H || p.nstrips != front8_strips(p.W)) return hipErrorInvalidValue;
+  if (windows < 1 || p.run_rows != front8_run_rows(windows) || p.nchunks * p.run_rows < p.H) return hipErrorInvalidValue;
   const size_t w8 = ((size_t)p.W + 7) / 8 * 8;
   if ((unsigned long long)p.H * p.in_pitch >= (1ull << 32) || p.in_pitch < (p.bgr ? 3 : 1) * w8) return hipErrorInvalidValue;
   if (p.prov_out && (p.W % 8 != 0)) return hipErrorInvalidValue;
   if (p.dbg_blur && p.dbg_pitch < w8) return hipErrorInvalidValue;
-  if (!p.dump || !p.zeros) return hipErrorInvalidValue;
+  if (!p.dump || !p.dump_c || !p.dump_p || !p.zeros) return hipErrorInvalidValue;
+  const int in_frames = p.bgr == 2 ? p.nframes / 3 : p.nframes, per = p.bgr == 2 ? 3 : 1;
+  if (p.half) {
+    // two half-strips per wave; half-wave B's frame is reached by 32-bit lane offsets (the caller sized dump / zeros for them)
+    const long units = (long)in_frames * p.nhalf;
+    if (p.nhalf != front8_half_strips(p.W) || (long)p.total_items != (units + 1) / 2 * p.nchunks * per) return hipErrorInvalidValue;
+    if ((unsigned long long)p.in_frame_stride + (unsigned long long)p.H * p.in_pitch >= (1ull << 32)) return hipErrorInvalidValue;
+    if (p.prov_out && (unsigned long long)per * p.prov_fs + (unsigned long long)p.H * p.prov_pitch >= (1ull << 32)) return hipErrorInvalidValue;
+  } else if (p.nstrips != front8_strips(p.W) || (long)p.total_items != (long)p.nframes * p.nstrips * p.nchunks) return hipErrorInvalidValue;
   return p.bgr == 2 ? launch_front8_t<2>(p, s) : p.bgr == 1 ? launch_front8_t<1>(p, s) : launch_front8_t<0>(p, s);
 }
 

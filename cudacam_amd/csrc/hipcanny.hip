@@ -91,7 +91,10 @@ struct hc_ctx {
   bool split_set = false;  // HC_OPT_FRONT_SPLIT was set by the caller
   int split = 2;        // Mode R front path: 2 = k_front8 (one kernel, 8 px per lane; default), 1 = k_blur + k_nms, 0 = the 4-px fused k_front
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
-  uint8_t *d_dump = nullptr;    // k_front8's dump area (FrontParams::dump), followed by its page of zeros (FrontParams::zeros)
+  int half_mode = -1;   // HC_OPT_FRONT_HALF: -1 automatic, 0 never, 1 whenever the buffers allow it
+  int dense_mode = -1;  // HC_OPT_FRONT_DENSE: -1 automatic, 0 never, 1 every window
+  uint8_t *d_dump = nullptr;    // k_front8's dump areas (FrontParams::dump / dump_c / dump_p), followed by its page of zeros (FrontParams::zeros)
+  size_t dump_region = 0;       // 0: the plain layout (16 KiB + 32 KiB); otherwise four regions of this size (the HALF form's lane offsets reach a frame further)
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
   size_t bplane_fs = 0, bplane_frames = 0;
   // HC_OPT_DEBUG_TAPS: copies of the bit planes as the front kernels left them, and (fused kernel) a plain blur plane
@@ -216,6 +219,24 @@ int ensure_blur_plane(hc_ctx *c)
   c->bplane_fs = (size_t)c->nstrips * c->H * 256;
   HIPCK(hipMalloc((void **)&c->d_bplane, c->bplane_fs * frames));
   c->bplane_frames = frames;
+  return HC_OK;
+}
+
+// k_front8's dump areas and page of zeros.  big: sized for the HALF form, whose half-wave B reaches its frame through lane
+// offsets of up to one frame stride (three bit-plane / output frames in per-channel mode)
+int alloc_dump(hc_ctx *c, bool big)
+{
+  if (c->d_dump && (c->dump_region != 0) == big) return HC_OK;
+  if (c->d_dump) { (void)hipFree(c->d_dump); c->d_dump = nullptr; }
+  size_t bytes = 16384 + 32768;
+  c->dump_region = 0;
+  if (big) {
+    const size_t plane_fs = sizeof(u32) * (size_t)c->RD * c->H;
+    c->dump_region = round_up(std::max(std::max(c->in_fs, 3 * c->out_fs), 3 * plane_fs) + 32768, 4096);
+    bytes = 4 * c->dump_region;
+  }
+  HIPCK(hipMalloc((void **)&c->d_dump, bytes));
+  HIPCK(hipMemset(c->d_dump, 0, bytes));
   return HC_OK;
 }
 
@@ -487,9 +508,14 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   // unaligned caller buffers go through the internal pitched ones
   const uint8_t *src = in;
   size_t sp = in_pitch, sfs = in_fs;
-  // (mode O on 3-channel data reads whole 12-byte groups of 4 pixels: a tighter caller pitch is staged as well)
+  // (mode O on 3-channel data reads whole 12-byte groups of 4 pixels: a tighter caller pitch is staged as well; so are
+  // rows that do not hold whole 8-pixel groups when the 8-px front kernels are to run -- k_front8 / k_front8o load 8 or
+  // 24 bytes per lane and row: tight rows of a width that is not a multiple of 8.  Round 2 fell back to the 4-px kernels
+  // for those; one copy through the internal pitched buffer keeps every frame on the one-kernel path)
   c->last_in_staged = 0;
-  if (!aligned4(in, in_pitch, in_fs) || (c->mode == HC_MODE_O && c->C == 3 && in_pitch < round_up((size_t)c->W, 4) * 3)) {
+  const bool wants8 = stage == HC_STAGE_HYSTER && c->split == 2 && (c->mode == HC_MODE_R || c->C == 1);
+  if (!aligned4(in, in_pitch, in_fs) || (c->mode == HC_MODE_O && c->C == 3 && in_pitch < round_up((size_t)c->W, 4) * 3)
+      || (wants8 && in_pitch < round_up((size_t)c->W, 8) * (size_t)c->C)) {
     c->last_in_staged = 1;
     if (int rc = copy_frames_d2d(c, sf, c->d_in, c->in_pitch, c->in_fs, in, in_pitch, in_fs, (size_t)W * c->C, n)) return rc;
     src = c->d_in; sp = c->in_pitch; sfs = c->in_fs;
@@ -563,17 +589,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     const bool can8 = sp >= round_up((size_t)W, 8) * (size_t)(fuse_bgr || c->per_channel ? 3 : 1);
     // Mode O: k_front8o (form 3) for one-channel sources, the 4-px k_front_o (form -1) for 3-channel ones, for rows that
     // do not hold whole 8-pixel groups, or when HC_OPT_FRONT_SPLIT asks for a 4-px form
-    // Narrow frames: a wave of k_front8 covers 496 columns whether or not they exist -- 640 columns cost two waves' worth
-    // (62.5 % of the lanes) -- while the 4-px kernels' strips are 248 columns wide (three strips, 83 %), at about 1.1 x
-    // the cost per lane: unless the caller chose a form, k_blur + k_nms take the widths where that pays (640 x 480:
-    // 1.61 against 1.32 M frames/s; 800 x 600 and 1280 x 720: k_front8 stays, 1.15 against 1.04 M and 729 against 658 k)
-    // -- for big batches only: one VGA frame per call takes 0.106 ms through k_front8 and 0.154 ms through the pair (two
-    // launches instead of one, and a blur plane between them)
-    const bool narrow4 = c->mode == HC_MODE_R && !c->split_set && (long long)n_out * H * W >= 100ll * 1000 * 1000
-                         && ((W + 247) / 248) * 256 * 110 < ((W + 495) / 496) * 512 * 90;  // (at least 7 % predicted)
-    const int form = c->mode != HC_MODE_R ? ((c->C == 1 && c->split == 2 && can8) ? 3 : -1) : (c->split == 2 && (!can8 || narrow4)) ? 1 : c->split;
+    // (Narrow frames: k_front8's HALF form, below.  Round 2 sent 640-column batches to k_blur + k_nms instead.)
+    const int form = c->mode != HC_MODE_R ? ((c->C == 1 && c->split == 2 && can8) ? 3 : -1) : (c->split == 2 && !can8) ? 1 : c->split;  // (!can8 cannot happen any more: such rows were staged above)
     const bool split = form == 1, f8 = form == 2 || form == 3;
-    c->last_front_form = form;
+    c->last_front_form = form;  // (4 when k_front8 runs in its half-strip form, below)
     // Pipelined mode: k_nms / k_front_o also write the strong pixels as 255 into the output (4 px per lane: whole
     // dwords need W % 4 == 0), so that the hysteresis, which runs beside the next run's bandwidth-hungry k_blur, only
     // rewrites the 16-pixel groups it changes instead of streaming out the whole map (+8 % end to end; without the
@@ -614,9 +633,28 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
 
     }
     if (f8) {  // strips of 496 columns, runs of 6 * windows - 4 rows
-      fp.dump = c->d_dump;
+      fp.dump = c->d_dump; fp.dump_c = c->d_dump + 2048; fp.dump_p = c->d_dump + 4096;
       fp.zeros = c->d_dump + 16384;
       fp.nstrips = front8_strips(W);
+      // dense path of k_front8 (wave-wide NMS): enter above 320 half-lanes per window of 768, leave below 256 -- the batch
+      // scheme costs 27 + 41 + 3.6 e instructions per row for e queued half-lanes, the dense path ~260
+      fp.dense_enter = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : 320;
+      fp.dense_leave = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : 256;
+      long waves_per_chunk = (long)n_out * fp.nstrips;
+      if (c->mode == HC_MODE_R && c->dump_region && c->half_mode != 0) {
+        // HALF form (narrow frames): the (frame, 240-column half-strip) units of a run of rows are dealt to half-waves in
+        // pairs -- 640 columns: 1.5 waves instead of 2 -- when that needs fewer waves and the lane offsets fit
+        const long per = c->per_channel ? 3 : 1, nh = front8_half_strips(W), pairs = ((long)n * nh + 1) / 2;
+        const size_t R = c->dump_region;
+        const bool fits = sfs + 32768 <= R && per * sizeof(u32) * (size_t)c->RD * H + 4096 <= R && (!s.prov || per * dfs + 16384 <= R)
+                          && (unsigned long long)sfs + (unsigned long long)H * sp < (1ull << 32) && (!s.prov || (unsigned long long)per * dfs + (unsigned long long)H * dp < (1ull << 32));
+        if ((pairs * per < waves_per_chunk || c->half_mode == 1) && fits) {
+          fp.half = 1; fp.nhalf = (int)nh;
+          fp.dump = c->d_dump; fp.dump_c = c->d_dump + R; fp.dump_p = c->d_dump + 2 * R; fp.zeros = c->d_dump + 3 * R;
+          waves_per_chunk = pairs * per;
+          c->last_front_form = 4;
+        }
+      }
       // runs of about 16 rounds of the chip for big batches (pick_run_rows); a small batch is cut into short runs instead --
       // down to 8 rows, where the 8-row warm-up doubles the work but one frame still spreads over 540 waves
       // Run length.  Every run repeats an 8-row warm-up, so long runs are cheaper -- measured optimum 110-180 rows at 1024
@@ -626,7 +664,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       int rows;
       if (c->chunk) rows = std::min(std::max(c->chunk, 2), H);
       else {
-        const long units = (long)n_out * fp.nstrips;
+        const long units = waves_per_chunk;
         long nch = std::max<long>(1, (H + 60) / 120);
         if (units * nch < 3072) nch = std::min<long>((3072 + units - 1) / units, std::max(1, H / 8));
         rows = (int)((H + nch - 1) / nch);
@@ -634,7 +672,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       const int windows = std::max(1, (rows + 4 + 5) / 6);
       fp.run_rows = front8_run_rows(windows);
       fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
-      fp.total_items = n_out * fp.nstrips * fp.nchunks;
+      fp.total_items = (int)(waves_per_chunk * fp.nchunks);
     }
     if (c->mode == HC_MODE_O) {
       // cv::Canny: plain thresholds on the L1 magnitude; long chunks (no LDS slab, 4-row warm-up)
@@ -789,7 +827,11 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch) == HC_OK;
   if (good && channels == 3) good = alloc_frames(&c->d_mono, &c->mono_pitch, &c->mono_fs, (size_t)width, height, max_batch) == HC_OK;
   good = good && alloc_slot(c, c->slot[0]) == HC_OK;
-  good = good && ok(hipMalloc((void **)&c->d_dump, 16384 + 32768), "hipMalloc(dump)") && ok(hipMemset(c->d_dump, 0, 16384 + 32768), "hipMemset(dump)");
+  {
+    // narrow frames take k_front8's HALF form when that needs fewer waves: an odd number of half-strips (pairs across frames)
+    const bool half_pays = front8_half_strips(width) % 2 == 1 || (front8_half_strips(width) + 1) / 2 < front8_strips(width);
+    good = good && alloc_dump(c, half_pays) == HC_OK;
+  }
   c->evpool.assign((size_t)hc_ctx::EV_RUNS * hc_ctx::EV_PER_RUN, nullptr);
   c->runprof.assign((size_t)hc_ctx::EV_RUNS, hc_ctx::RunProf{});
   for (size_t i = 0; good && i < c->evpool.size(); ++i) good = ok(hipEventCreate(&c->evpool[i]), "hipEventCreate");
@@ -888,6 +930,17 @@ int hc_set_option(hc_ctx *c, int option, int value)
     if (value < 0 || value > 2) return fail(HC_E_ARG, "HC_OPT_FRONT_SPLIT: 0 (k_front), 1 (k_blur + k_nms) or 2 (k_front8)");
     c->split = value;
     c->split_set = true;  // the caller's choice: no automatic switch to the 4-px pair for narrow frames
+  } else if (option == HC_OPT_FRONT_DENSE) {
+    if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_DENSE: -1 (automatic), 0 (never) or 1 (every window)");
+    c->dense_mode = value;
+  } else if (option == HC_OPT_FRONT_HALF) {
+    if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_HALF: -1 (automatic), 0 (never) or 1 (whenever possible)");
+    HIPCK(hipSetDevice(c->device));
+    if (value == 1 && !c->dump_region) {  // the half-strip form needs the larger dump areas
+      HIPCK(hipDeviceSynchronize());
+      if (int rc = alloc_dump(c, true)) return rc;
+    }
+    c->half_mode = value;
   } else if (option == HC_OPT_L2_GRADIENT) {
     if (c->mode != HC_MODE_O) return fail(HC_E_ARG, "HC_OPT_L2_GRADIENT applies to mode O contexts");
     c->l2gradient = value != 0;

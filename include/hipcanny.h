@@ -143,9 +143,9 @@ int hc_hysteresis_totals(hc_ctx *ctx, unsigned long long totals[4], int reset);
 /* What the last hc_run / hc_run_device did with the caller's buffers -- no silent cliffs: *input_staged / *output_staged are
  * 1 when the frames went through the context's internal pitched buffers (an extra device-to-device copy each: pointer,
  * pitch or frame stride not a multiple of 4, or 3-channel mode O rows without whole 12-byte groups), and *front_form is
- * the front path that ran (Mode R: the HC_OPT_FRONT_SPLIT value 2 / 1 / 0; Mode O: 3 = k_front8o, -1 = k_front_o; -1
- * also for final stages below HYSTER): a context set to k_front8 falls back to k_blur + k_nms (Mode O: to k_front_o)
- * when a row does not hold whole 8-pixel groups. */
+ * the front path that ran (Mode R: the HC_OPT_FRONT_SPLIT value 2 / 1 / 0, or 4 = k_front8 in its half-strip form; Mode O:
+ * 3 = k_front8o, -1 = k_front_o; -1 also for final stages below HYSTER).  Rows that do not hold whole 8-pixel groups
+ * (tight rows of a width that is not a multiple of 8) are staged (*input_staged = 1) so that the 8-px kernels can run. */
 int hc_last_run_info(hc_ctx *ctx, int *input_staged, int *output_staged, int *front_form);
 
 /* Pipelined mode: how many runs of `nframes` frames the context keeps in flight (2, or 4 for small batches -- fewer
@@ -199,8 +199,19 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
 /*
  * HC_OPT_DEBUG_TAPS (default 0): parity-test diagnostics.  1 = every HC_STAGE_HYSTER run keeps a copy of what the
  * FAST path's front kernels produced -- the STRONG and CANDIDATE bit planes as they are handed to the hysteresis,
- * and the blur plane (Mode R) -- for hc_debug_tap().  Costs two plane copies per run; never set it when timing. */
-enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6 };
+ * and the blur plane (Mode R) -- for hc_debug_tap().  Costs two plane copies per run; never set it when timing.
+ *
+ * HC_OPT_FRONT_HALF (default -1 = automatic, Mode R): the half-strip form of k_front8 for narrow frames -- a wave is two
+ * independent half-waves of 240 columns each, and the (frame, half-strip) units of a run of rows are dealt to them in pairs
+ * (640 columns: 1.5 waves per frame instead of 2).  -1 = when it needs fewer waves; 0 = never; 1 = whenever the buffers
+ * allow it (parity tests).  hc_last_run_info reports it as front form 4.
+ *
+ * HC_OPT_FRONT_DENSE (default -1 = automatic, Mode R): k_front8's dense path -- a window of 6 rows that follows one in
+ * which more than 320 of the wave's 768 half-lanes passed the low threshold (noise, texture) is processed by wave-wide
+ * non-maximum suppression in registers instead of the queue and its batches, until a window counts fewer than 256.
+ * 0 = never, 1 = every window (parity tests).  Same results either way. */
+enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6, HC_OPT_FRONT_HALF = 7,
+       HC_OPT_FRONT_DENSE = 8 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* The fast path's own intermediates of the last HC_STAGE_HYSTER run (HC_OPT_DEBUG_TAPS must have been set before it),

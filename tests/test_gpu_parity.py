@@ -633,8 +633,9 @@ def test_pipelined_mixed_schedule_continuation(oracle, k):
 
 
 def test_last_run_info_reports_form_and_staging(oracle):
-    """Aligned caller buffers are used in place by k_front8; a row that does not hold whole 8-pixel groups falls back to
-    k_blur + k_nms (and says so); mode O reports k_front8o (3), or the 4-px k_front_o (-1) when asked for a 4-px form."""
+    """Aligned caller buffers are used in place by k_front8; a row that does not hold whole 8-pixel groups is staged
+    through the internal pitched buffer (and says so); mode O reports k_front8o (3), or the 4-px k_front_o (-1) when
+    asked for a 4-px form."""
     import torch
     img = synth.natural(640, 100, 3)
     d_in = torch.from_numpy(img).cuda()
@@ -661,8 +662,8 @@ def test_last_run_info_reports_form_and_staging(oracle):
     with api.Context(644, 60, 1, 1) as ctx:
         ctx.run_device(d_in2.data_ptr(), 644, 644 * 60, d_out2.data_ptr(), 644, 644 * 60, 1)
         ctx.sync()
-        assert ctx.last_run_info() == (False, False, 1)
-        _diff(d_out2.cpu().numpy(), oracle.canny_r(img2, 10, 40), "fallback to the 4-px kernels")
+        assert ctx.last_run_info() == (True, False, 2)   # staged onto the 8-px kernel (round 2: fell back to k_blur + k_nms)
+        _diff(d_out2.cpu().numpy(), oracle.canny_r(img2, 10, 40), "ragged tight rows, staged")
     with api.Context(640, 100, 1, 1, mode=api.MODE_O) as ctx:
         ctx.run_device(d_in.data_ptr(), 640, 640 * 100, d_out.data_ptr(), 640, 640 * 100, 1)
         ctx.sync()
