@@ -362,8 +362,23 @@ def host_fed(a, d_in):
         lib.hc_host_free(C.c_void_p(hin))
         lib.hc_host_free(C.c_void_p(hout))
     frames = nbatches * nb
-    return {"value": round(frames / dt, 1), "unit": "frames/s", "batch": nb, "batches": nbatches, "contexts": 3, "staging": "page-locked (hc_host_alloc)",
-            "pcie_GBps_each_way": round(frames * frame_in / dt / 1e9, 2), "note": "frames start and end in host memory; one staging thread"}
+    out = {"value": round(frames / dt, 1), "unit": "frames/s", "batch": nb, "batches": nbatches, "contexts": 3, "staging": "page-locked (hc_host_alloc)",
+           "pcie_GBps_each_way": round(frames * frame_in / dt / 1e9, 2), "note": "frames start and end in host memory; one staging thread (Python twin of cvp::io::FrameStreamer)"}
+    # the C++ host pipeline itself (tools/stream_bench.cpp over cvp::io::FrameStreamer), as a child process: with the staging
+    # buffers already filled (a decoder that writes straight into stage()), and with a 4-thread producer copying every batch in
+    exe = os.path.join(ROOT, "tools", "bin", "stream_bench")
+    if os.path.exists(exe) and a.mode == "R" and not a.per_channel:
+        import subprocess
+        out["cxx_streamer"] = {}
+        for name, prod in (("staging_prefilled", 0), ("producer_4_threads", 4)):
+            try:
+                r = subprocess.run([exe, "--width", str(W), "--height", str(H), "--channels", str(ch), "--batch", str(nb), "--batches", str(max(20, nbatches)), "--producer", str(prod)],
+                                   capture_output=True, text=True, timeout=120)
+                line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+                out["cxx_streamer"][name] = json.loads(line[-1]) if r.returncode == 0 and line else {"error": (r.stderr or r.stdout)[-300:]}
+            except Exception as e:   # a missing runtime library, a timeout: reported, never fatal to the bench line
+                out["cxx_streamer"][name] = {"error": f"{type(e).__name__}: {e}"}
+    return out
 
 
 def cpu_baseline(a, d_ins, checks):

@@ -47,6 +47,9 @@ constexpr int F8_RING = F8_SUB + 4;                // rows kept in each LDS ring
 constexpr int F8_FQ = 128;                         // flagged-pixel queue entries per window (expected fill ~20); [F8_FQ] is a dump slot
 constexpr int F8_NQ = 512;                         // NMS queue (ids), circular; [F8_NQ] is a dump slot
 constexpr int F8_ROW_BYTES = 64 * 8;
+#ifndef F8_WPB
+#define F8_WPB 4  // waves per workgroup of k_front8 (mono / BGR; per-channel mode: 3, one per channel).  The waves are independent.
+#endif
 #ifndef F8_LDS_PAD
 #define F8_LDS_PAD 0  // experiments: extra LDS per wave (occupancy studies)
 #endif
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   // strip, run), a wave each, kept within one window of each other by a barrier per window -- so the 24 interleaved bytes
   // per lane and row are fetched from HBM once and served to the other two waves from the CU's L1 / the XCD's L2.
   // (Without the barrier the three drifted apart and the input was fetched about twice: 5.5 GB per 16 8K frames.)
-  constexpr int WPB = IN == 2 ? 3 : 4;
+  constexpr int WPB = IN == 2 ? 3 : F8_WPB;
   int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPB + wib);
   if (item >= p.total_items) return;  // (per-channel: total_items is a multiple of 3, a workgroup leaves as a whole)
   int ch = 0;
@@ -1006,7 +1009,7 @@ __global__ __launch_bounds__(256) void k_front8o(const FrontParams p)
 template <int IN>
 static hipError_t launch_front8_t(const FrontParams &p, hipStream_t s)
 {
-  constexpr int WPB = IN == 2 ? 3 : 4;
+  constexpr int WPB = IN == 2 ? 3 : F8_WPB;
   if (IN == 2 && p.total_items % 3 != 0) return hipErrorInvalidValue;
   const dim3 grid((unsigned)((p.total_items + WPB - 1) / WPB)), block(64 * WPB);
   const size_t lds = (size_t)WPB * F8_WAVE_BYTES;

@@ -612,8 +612,13 @@ def test_pipelined_mixed_schedule_continuation(oracle, k):
     worklist and the rest take lists.  With only 3 or 4 launches queued on a serpentine frame the host-side continuation
     is certain, and it must replay THAT schedule (Slot::mixed_from), not the parameters of the run's last launch."""
     import torch
-    w, h = 1000, 1100
-    serp = synth.serpentine(w, h)
+    w, h = 1000, 2300
+    # a weak vertical line down the whole frame with one strong head: every one of the 18 row tiles must be crossed, one
+    # per launch (the boustrophedon frame of synth.serpentine settles in three launches at this size)
+    serp = np.zeros((h, w), np.uint8)
+    serp[:, 100:140] = 20
+    for r in range(20):   # the head fades into the line, so that the strong edge and the weak one are connected
+        serp[r, 100:140] = 120 - 5 * r
     nat = synth.natural(w, h, 78)
     frames = np.stack([serp, nat])
     want = oracle.canny_r_batch(frames, 10, 40, threads=4)
@@ -622,14 +627,15 @@ def test_pipelined_mixed_schedule_continuation(oracle, k):
     with api.Context(w, h, 1, 2) as ctx:
         ctx.set_option(api.OPT_PIPELINE, 1)
         ctx.set_tuning(0, k)
+        ctx.hysteresis_totals(reset=True)
         for r in range(3):
             ctx.run_device(d_in.data_ptr(), w, w * h, d_out[r % 2].data_ptr(), w, w * h, 2)
         ctx.sync()
-        _, continued = ctx.hysteresis_info()
-        assert continued == 1
+        runs, continued, work, queued = ctx.hysteresis_totals()
         for o in d_out:
             for f in range(2):
                 _diff(o.cpu().numpy()[f], want[f], f"mixed schedule, {k} launches queued, frame {f}")
+        assert runs == 3 and queued == 3 * k and continued >= 1, (runs, continued, work, queued)
 
 
 def test_last_run_info_reports_form_and_staging(oracle):
