@@ -323,13 +323,14 @@ def host_fed(a, d_in):
     (include/cvp/frameIO.hpp).  Bounded: about a second of work."""
     import ctypes as C
     lib = api.load_library()
-    nb = min(16, d_in.shape[0])
+    nb = min(32, d_in.shape[0])   # 64 MiB of 1080p frames per batch: below that the hand-over between copies and kernels shows (tools/pcie_raw2.hip)
     ch = a.channels
     frame_in, frame_out = W * H * ch, W * H * (3 if a.per_channel else 1)
     host_frames = d_in[:nb].cpu().numpy()
     ring = []
     for _ in range(3):
         ctx = api.Context(W, H, ch, nb, api.MODE_R if a.mode == "R" else api.MODE_O)
+        ctx.set_option(api.OPT_COPY_STREAMS, 1)
         if a.per_channel:
             ctx.set_option(api.OPT_PER_CHANNEL, 1)
         ctx.set_thresholds(LOW, HIGH)
@@ -340,22 +341,27 @@ def host_fed(a, d_in):
     busy = [False] * 3
 
     def finish(k):
-        ctx, _, hout = ring[k]
-        api._ck(lib.hc_download(ctx.handle, C.c_void_p(hout), W, W * H, nb * (3 if a.per_channel else 1)))
+        api._ck(lib.hc_download_end(ring[k][0].handle))
         busy[k] = False
 
+    def stream(count):
+        for i in range(count):
+            k = i % 3
+            if busy[k]:
+                finish(k)
+            ctx, hin, hout = ring[k]
+            api._ck(lib.hc_upload(ctx.handle, C.c_void_p(hin), W * ch, frame_in, nb))
+            ctx.run(api.CannyStage.HYSTER, nb)
+            # the download is queued behind the run at once: it crosses PCIe while the next batches upload
+            api._ck(lib.hc_download_begin(ctx.handle, C.c_void_p(hout), W, W * H, nb * (3 if a.per_channel else 1)))
+            busy[k] = True
+        for k in range(3):
+            if busy[(count + k) % 3]:
+                finish((count + k) % 3)
+
+    stream(6)   # warm: first-touch of the page-locked buffers, first launches of every context
     t0 = time.perf_counter()
-    for i in range(nbatches):
-        k = i % 3
-        if busy[k]:
-            finish(k)
-        ctx, hin, _ = ring[k]
-        api._ck(lib.hc_upload(ctx.handle, C.c_void_p(hin), W * ch, frame_in, nb))
-        ctx.run(api.CannyStage.HYSTER, nb)
-        busy[k] = True
-    for k in range(3):
-        if busy[(nbatches + k) % 3]:
-            finish((nbatches + k) % 3)
+    stream(nbatches)
     dt = time.perf_counter() - t0
     for ctx, hin, hout in ring:
         ctx.close()

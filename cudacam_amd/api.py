@@ -47,6 +47,7 @@ OPT_L2_GRADIENT = 5
 OPT_DEBUG_TAPS = 6
 OPT_FRONT_HALF = 7
 OPT_FRONT_DENSE = 8
+OPT_COPY_STREAMS = 9
 TAP_BLUR, TAP_THRESH = 1, 2
 
 # every symbol include/hipcanny.h declares
@@ -55,7 +56,7 @@ ABI_SYMBOLS = [
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
     "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals", "hc_last_run_info", "hc_pipeline_depth",
-    "hc_profile_get_front_each", "hc_hysteresis_totals",
+    "hc_profile_get_front_each", "hc_hysteresis_totals", "hc_download_begin", "hc_download_end",
 ]
 
 _lib = None
@@ -102,6 +103,8 @@ def load_library():
     L.hc_run_device.argtypes = [vp, vp, sz, sz, vp, sz, sz, i, i]
     L.hc_hysteresis_device.argtypes = [vp, vp, sz, sz, vp, sz, sz, i]
     L.hc_download.argtypes = [vp, vp, sz, sz, i]
+    L.hc_download_begin.argtypes = [vp, vp, sz, sz, i]
+    L.hc_download_end.argtypes = [vp]
     L.hc_sync.argtypes = [vp]
     L.hc_set_stream.argtypes = [vp, vp]
     L.hc_use_own_stream.argtypes = [vp]

@@ -223,6 +223,8 @@ namespace io
     for (Slot &s : m_slots) {
       s.ctx = hc_create(device, m_w, m_h, m_c, m_batch, mode == 1 ? HC_MODE_O : HC_MODE_R);
       if (!s.ctx) die("hc_create");
+      // uploads and downloads of all slots on the device's two copy streams: both directions of the link stay busy
+      if (hc_set_option(s.ctx, HC_OPT_COPY_STREAMS, 1) != HC_OK) die("hc_set_option(HC_OPT_COPY_STREAMS)");
       s.hostIn = static_cast<std::uint8_t *>(hc_host_alloc(inBytes));
       s.hostOut = static_cast<std::uint8_t *>(hc_host_alloc(outBytes));
       if (!s.hostIn || !s.hostOut) die("hc_host_alloc");
@@ -252,8 +254,9 @@ namespace io
   void FrameStreamer::complete(Slot &s, const Sink &sink)
   {
     if (!s.busy) return;
-    // waits for this slot's stream only; the other slots keep uploading / computing meanwhile
-    if (hc_download(s.ctx, s.hostOut, static_cast<std::size_t>(m_w), static_cast<std::size_t>(m_w) * m_h, s.n) != HC_OK) die("hc_download");
+    // waits for this slot's stream only -- its download was queued behind its run by commit() -- while the other slots
+    // keep uploading / computing
+    if (hc_download_end(s.ctx) != HC_OK) die("hc_download_end");
     s.busy = false;
     if (sink) sink(s.hostOut, s.n, s.first);
   }
@@ -268,6 +271,8 @@ namespace io
     const std::size_t row = static_cast<std::size_t>(m_w) * m_c;
     if (hc_upload(s.ctx, s.hostIn, row, row * m_h, n) != HC_OK) die("hc_upload");                  // asynchronous: page-locked source
     if (hc_run(s.ctx, HC_STAGE_HYSTER, n) != HC_OK) die("hc_run");                                   // asynchronous
+    // ... and so is the download: queued now, it moves over PCIe while the NEXT batches upload (both directions at once)
+    if (hc_download_begin(s.ctx, s.hostOut, static_cast<std::size_t>(m_w), static_cast<std::size_t>(m_w) * m_h, n) != HC_OK) die("hc_download_begin");
     s.busy = true;
     m_in += n;
     m_head = (m_head + 1) % static_cast<int>(m_slots.size());

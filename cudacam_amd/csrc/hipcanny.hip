@@ -15,6 +15,9 @@
 using namespace hc;
 
 namespace {
+// the two copy streams all HC_OPT_COPY_STREAMS contexts of a device share (created on first use, kept for the process)
+constexpr int MAX_DEVICES = 64;
+hipStream_t g_h2d[MAX_DEVICES] = { nullptr }, g_d2h[MAX_DEVICES] = { nullptr };
 thread_local std::string g_err;
 int fail(int code, const std::string &msg)
 {
@@ -115,6 +118,12 @@ struct hc_ctx {
   int hyst_need_rows = 0;  // launches that found work in recent runs (continuation rounds included) x rows per tile: how far changes travelled
   u32 h_stats[3 * MAX_HYST_LAUNCHES] = { 0 };
   int uploaded = 0, last_run_n = 0;
+  int last_slot = 0;          // slot of the most recent fused run
+  // hc_download_begin .. hc_download_end
+  uint8_t *dl_host = nullptr; size_t dl_row = 0, dl_fs = 0; int dl_n = 0;
+  // HC_OPT_COPY_STREAMS: uploads / downloads on the device's shared copy streams, tied to the context stream by events
+  bool copy_streams = false;
+  hipEvent_t ev_up = nullptr, ev_ready = nullptr, ev_ready2 = nullptr, ev_down = nullptr;
   bool profiling = false;
   // hipEvent ring: up to EV_PER_RUN events per profiled run.  Interval i = ev[i] -> ev[i + 1] covers the reference stages
   // in RunProf::mask[i] (one kernel may cover several: its time is divided equally among them, see hc_stage_time_ms)
@@ -764,6 +773,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     c->ev_count++;
   }
   if (stage == HC_STAGE_HYSTER) HIPCK(hipEventRecord(s.ev_done, sh));
+  c->last_slot = piped ? c->cur : 0;
   if (piped) c->cur = (c->cur + 1) % c->nslot_use;
   c->last_run_n = n_out;
   return HC_OK;
@@ -860,6 +870,7 @@ void hc_destroy(hc_ctx *c)
   for (Slot &q : c->slot) free_slot(q);
   free_debug_buffers(c);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : { c->ev_up, c->ev_ready, c->ev_ready2, c->ev_down }) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -934,6 +945,18 @@ int hc_set_option(hc_ctx *c, int option, int value)
     if (value < 0 || value > 2) return fail(HC_E_ARG, "HC_OPT_FRONT_SPLIT: 0 (k_front), 1 (k_blur + k_nms) or 2 (k_front8)");
     c->split = value;
     c->split_set = true;  // the caller's choice: no automatic switch to the 4-px pair for narrow frames
+  } else if (option == HC_OPT_COPY_STREAMS) {
+    if (c->dl_host) return fail(HC_E_STATE, "HC_OPT_COPY_STREAMS: a download is in flight");
+    HIPCK(hipSetDevice(c->device));
+    if (value && c->device < MAX_DEVICES) {
+      if (!g_h2d[c->device]) HIPCK(hipStreamCreateWithFlags(&g_h2d[c->device], hipStreamNonBlocking));
+      if (!g_d2h[c->device]) HIPCK(hipStreamCreateWithFlags(&g_d2h[c->device], hipStreamNonBlocking));
+      if (!c->ev_up) HIPCK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
+      if (!c->ev_ready) HIPCK(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+      if (!c->ev_ready2) HIPCK(hipEventCreateWithFlags(&c->ev_ready2, hipEventDisableTiming));
+      if (!c->ev_down) HIPCK(hipEventCreateWithFlags(&c->ev_down, hipEventDisableTiming));
+    }
+    c->copy_streams = value != 0 && c->device < MAX_DEVICES;
   } else if (option == HC_OPT_FRONT_DENSE) {
     if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_DENSE: -1 (automatic), 0 (never) or 1 (every window)");
     c->dense_mode = value;
@@ -970,11 +993,20 @@ int hc_upload(hc_ctx *c, const uint8_t *host, size_t row_stride, size_t frame_st
   HIPCK(hipSetDevice(c->device));
   if (int rc = finish_all(c)) return rc;
   // cannyEdgeH.cu:136/144 (cudaMemcpy2D host -> pitched device).  Tight rows on both sides: one contiguous block, one DMA
+  hipStream_t cs = c->copy_streams ? g_h2d[c->device] : c->stream;
+  if (c->copy_streams && hipStreamQuery(c->stream) != hipSuccess) {  // what is still queued on the context stream (it may read d_in) comes first
+    HIPCK(hipEventRecord(c->ev_ready, c->stream));
+    HIPCK(hipStreamWaitEvent(cs, c->ev_ready, 0));
+  }
   if (row_stride == rb && c->in_pitch == rb && frame_stride == c->in_fs)
-    HIPCK(hipMemcpyAsync(c->d_in, host, c->in_fs * (size_t)n, hipMemcpyHostToDevice, c->stream));
+    HIPCK(hipMemcpyAsync(c->d_in, host, c->in_fs * (size_t)n, hipMemcpyHostToDevice, cs));
   else
     for (int f = 0; f < n; ++f)
-      HIPCK(hipMemcpy2DAsync(c->d_in + c->in_fs * f, c->in_pitch, host + frame_stride * f, row_stride, rb, (size_t)c->H, hipMemcpyHostToDevice, c->stream));
+      HIPCK(hipMemcpy2DAsync(c->d_in + c->in_fs * f, c->in_pitch, host + frame_stride * f, row_stride, rb, (size_t)c->H, hipMemcpyHostToDevice, cs));
+  if (c->copy_streams) {
+    HIPCK(hipEventRecord(c->ev_up, cs));
+    HIPCK(hipStreamWaitEvent(c->stream, c->ev_up, 0));
+  }
   c->uploaded = n;
   return HC_OK;
 }
@@ -984,6 +1016,7 @@ int hc_run(hc_ctx *c, int final_stage, int n)
   if (!c) return fail(HC_E_ARG, "null context");
   if (final_stage < HC_STAGE_MONO || final_stage > HC_STAGE_HYSTER) return fail(HC_E_ARG, "Canny Stage Not Recognized");
   if (n <= 0 || n > c->uploaded) return fail(HC_E_STATE, "hc_run: more frames than uploaded");
+  if (c->dl_host) return fail(HC_E_STATE, "hc_run: a download of the internal output buffer is in flight (hc_download_end first)");
   HIPCK(hipSetDevice(c->device));
   return run_impl(c, c->d_in, c->in_pitch, c->in_fs, c->d_out, c->out_pitch, c->out_fs, n, final_stage);
 }
@@ -1085,6 +1118,54 @@ int hc_download(hc_ctx *c, uint8_t *host, size_t row_stride, size_t frame_stride
       HIPCK(hipMemcpy2DAsync(host + frame_stride * f, row_stride, c->d_out + c->out_fs * f, c->out_pitch, (size_t)c->W, (size_t)c->H, hipMemcpyDeviceToHost, c->stream));
   HIPCK(hipStreamSynchronize(c->stream));
   return HC_OK;
+}
+
+namespace {
+int queue_download(hc_ctx *c)
+{
+  hipStream_t cs = c->copy_streams ? g_d2h[c->device] : c->stream;
+  if (c->copy_streams) {  // behind everything queued on the context stream (the run, its copy-out kernels)
+    HIPCK(hipEventRecord(c->ev_ready2, c->stream));
+    HIPCK(hipStreamWaitEvent(cs, c->ev_ready2, 0));
+    Slot &s = c->slot[c->last_slot];
+    if (s.pending && s.stream != c->stream) HIPCK(hipStreamWaitEvent(cs, s.ev_done, 0));
+  }
+  if (c->dl_row == (size_t)c->W && c->out_pitch == (size_t)c->W && c->dl_fs == c->out_fs)
+    HIPCK(hipMemcpyAsync(c->dl_host, c->d_out, c->out_fs * (size_t)c->dl_n, hipMemcpyDeviceToHost, cs));
+  else
+    for (int f = 0; f < c->dl_n; ++f)
+      HIPCK(hipMemcpy2DAsync(c->dl_host + c->dl_fs * f, c->dl_row, c->d_out + c->out_fs * f, c->out_pitch, (size_t)c->W, (size_t)c->H, hipMemcpyDeviceToHost, cs));
+  if (c->copy_streams) HIPCK(hipEventRecord(c->ev_down, cs));
+  return HC_OK;
+}
+}  // namespace
+
+int hc_download_begin(hc_ctx *c, uint8_t *host, size_t row_stride, size_t frame_stride, int n)
+{
+  if (!c || !host) return fail(HC_E_ARG, "hc_download_begin: null argument");
+  if (n <= 0 || n > c->last_run_n) return fail(HC_E_STATE, "hc_download_begin: more frames than the last run produced");
+  if (row_stride < (size_t)c->W) return fail(HC_E_ARG, "hc_download_begin: row_stride smaller than a row");
+  if (c->dl_host) return fail(HC_E_STATE, "hc_download_begin: a download is already in flight (hc_download_end first)");
+  HIPCK(hipSetDevice(c->device));
+  // behind the run: its hysteresis may sit on the slot's own stream (pipelined mode)
+  Slot &s = c->slot[c->last_slot];
+  if (s.pending && s.stream != c->stream) HIPCK(hipStreamWaitEvent(c->stream, s.ev_done, 0));
+  c->dl_host = host; c->dl_row = row_stride; c->dl_fs = frame_stride; c->dl_n = n;
+  if (int rc = queue_download(c)) { c->dl_host = nullptr; return rc; }
+  return HC_OK;
+}
+
+int hc_download_end(hc_ctx *c)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  if (!c->dl_host) return fail(HC_E_STATE, "hc_download_end without hc_download_begin");
+  HIPCK(hipSetDevice(c->device));
+  const unsigned long long continued_before = c->hyst_totals[1];
+  int rc = finish_all(c);  // convergence of every run in flight; the host-side continuation if one needed it
+  if (rc == HC_OK && c->hyst_totals[1] != continued_before) rc = queue_download(c);  // the maps changed after the copy was queued
+  if (rc == HC_OK && (c->copy_streams ? hipEventSynchronize(c->ev_down) : hipStreamSynchronize(c->stream)) != hipSuccess) rc = fail(HC_E_HIP, "waiting for the download failed");
+  c->dl_host = nullptr;
+  return rc;
 }
 
 int hc_enable_profiling(hc_ctx *c, int on)

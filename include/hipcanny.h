@@ -86,6 +86,15 @@ int hc_hysteresis_device(hc_ctx *ctx, const void *d_thresh, size_t in_pitch, siz
  * GL PBO; a headless MI355X has no GL: this is the generalised sink). Synchronises. */
 int hc_download(hc_ctx *ctx, uint8_t *host, size_t row_stride, size_t frame_stride, int nframes);
 
+/* The same in two halves, for host pipelines that keep several contexts busy (cvp::io::FrameStreamer): _begin queues the
+ * device -> host copy of the last run's output images behind that run and returns at once -- so that the copy engine
+ * has this context's download queued while the host goes on to upload and start the next context's batch (PCIe carries
+ * both directions at once: 48 GB/s each way on the GPU box against 54 / 56 one at a time) -- and _end waits for it,
+ * verifies the run's convergence and, in the rare case the hysteresis had to be continued from the host, repeats the
+ * copy.  `host` should be page-locked (hc_host_alloc); it must stay valid until _end returns. */
+int hc_download_begin(hc_ctx *ctx, uint8_t *host, size_t row_stride, size_t frame_stride, int nframes);
+int hc_download_end(hc_ctx *ctx);
+
 /* Waits for the context stream; also completes the rare hysteresis continuation. */
 int hc_sync(hc_ctx *ctx);
 
@@ -209,9 +218,16 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * HC_OPT_FRONT_DENSE (default -1 = automatic, Mode R): k_front8's dense path -- a window of 6 rows that follows one in
  * which more than 320 of the wave's 768 half-lanes passed the low threshold (noise, texture) is processed by wave-wide
  * non-maximum suppression in registers instead of the queue and its batches, until a window counts fewer than 256.
- * 0 = never, 1 = every window (parity tests).  Same results either way. */
+ * 0 = never, 1 = every window (parity tests).  Same results either way.
+ *
+ * HC_OPT_COPY_STREAMS (default 0): host pipelines of several contexts (cvp::io::FrameStreamer).  1 = hc_upload and
+ * hc_download_begin move their data on two copy streams that ALL such contexts of a device share -- one for host ->
+ * device, one for device -> host -- tied to the context stream by events, instead of on the context stream itself.
+ * Copies that share a stream with kernels do not overlap across contexts on this runtime (three contexts, 32 MiB
+ * batches: 28 GB/s each way; with the two copy streams 40, with 64 MiB batches 47 of the 48 GB/s the link carries both
+ * ways at once -- tools/pcie_raw2.hip). */
 enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6, HC_OPT_FRONT_HALF = 7,
-       HC_OPT_FRONT_DENSE = 8 };
+       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* The fast path's own intermediates of the last HC_STAGE_HYSTER run (HC_OPT_DEBUG_TAPS must have been set before it),

@@ -680,3 +680,38 @@ def test_last_run_info_reports_form_and_staging(oracle):
         ctx.sync()
         assert ctx.last_run_info() == (False, False, -1)
         _diff(d_out.cpu().numpy(), oracle.canny_o(img, 50, 150), "mode O, 4-px kernel")
+
+
+def test_download_begin_end(oracle):
+    """hc_download_begin queues the device -> host copy behind the run and returns; hc_download_end waits, verifies the
+    convergence and -- when the hysteresis had to be continued from the host (one launch queued, a frame that needs 18) --
+    repeats the copy: the host buffer must hold the final maps either way."""
+    lib = api.load_library()
+    w, h = 1000, 2300
+    line = np.zeros((h, w), np.uint8)
+    line[:, 100:140] = 20
+    for r in range(20):
+        line[r, 100:140] = 120 - 5 * r
+    frames = np.stack([line, synth.natural(w, h, 79)])
+    want = oracle.canny_r_batch(frames, 10, 40, threads=4)
+    hout = lib.hc_host_alloc(2 * w * h)
+    try:
+        for launches in (0, 1):
+            with api.Context(w, h, 1, 2) as ctx:
+                ctx.set_tuning(0, launches)
+                ctx.hysteresis_totals(reset=True)
+                for _ in range(2):
+                    ctx.upload(frames)
+                    ctx.run(api.CannyStage.HYSTER, 2)
+                    api._ck(lib.hc_download_begin(ctx.handle, C.c_void_p(hout), w, w * h, 2))
+                    assert lib.hc_download_begin(ctx.handle, C.c_void_p(hout), w, w * h, 2) != 0   # one download at a time
+                    api._ck(lib.hc_download_end(ctx.handle))
+                    got = np.ctypeslib.as_array((C.c_uint8 * (2 * w * h)).from_address(hout)).reshape(2, h, w)
+                    for f in range(2):
+                        _diff(got[f], want[f], f"download_begin/end, {launches} launches queued, frame {f}")
+                    got[:] = 7
+                assert lib.hc_download_end(ctx.handle) != 0   # nothing in flight
+                if launches == 1:
+                    assert ctx.hysteresis_totals()[1] == 2, "the one-launch runs were not continued from the host"
+    finally:
+        lib.hc_host_free(C.c_void_p(hout))
