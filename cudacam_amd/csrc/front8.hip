@@ -490,7 +490,11 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   // the non-strict NMS of the 6 output rows against the rows above / below in registers and the neighbours' columns by
   // DPP -> one byte of each plane and 8 bytes of provisional map per lane and row, stored once (no zero-stores, no queue,
   // no LDS beyond the 10 row reads).  ~260 instructions per row whatever the content.  The arithmetic is the batch's.
+#ifdef F8_NO_DENSE  // experiments: the kernel without the dense path
+  constexpr bool dense = false;
+#else
   bool dense = p.dense_enter < 0;  // this window takes the dense path (HC_OPT_FRONT_DENSE = 1: every window, tests)
+#endif
   auto dense_window = [&](int bw0, u32 sbase) {
     // pixels outside the image have zero gradients (cannyEdgeD.cu:142-149, 222-229): half-word masks of the lane's aligned pairs
     const u32 pm[4] = { __builtin_amdgcn_perm(0u, cmask[0], 0x01010000u), __builtin_amdgcn_perm(0u, cmask[0], 0x03030202u),
@@ -680,7 +684,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     }
     int sb = bslot0 - 4;  // blur-ring slot of blur row bw0 - 4
     if (sb < 0) sb += F8_RING;
-    if (dense) {
+    if (__builtin_expect(dense, false)) {  // (laid out after the kernel's hot blocks)
       dense_window(bw0, (u32)sb);
     } else {
       wq = 0;
@@ -694,7 +698,9 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
       while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
     }
     // the next window: dense when this one queued (or, on the dense path, counted) many half-lanes; with hysteresis
+#ifndef F8_NO_DENSE
     dense = wq > (dense ? p.dense_leave : p.dense_enter);
+#endif
     wave_lds_sync();  // the next window's phase 1 overwrites the oldest ring rows
     if (IN == 2) __syncthreads();  // the three channels of this run stay within a window of each other (see above)
     bslot0 = bslot0 + F8_SUB >= F8_RING ? bslot0 + F8_SUB - F8_RING : bslot0 + F8_SUB;

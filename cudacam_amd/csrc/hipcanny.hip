@@ -89,6 +89,7 @@ struct hc_ctx {
   size_t wl_prev_tiles = 0;                    // ... and its tile count (0: none / not a wide-frame run)
   bool hyst_lists_last = false;        // the last run used the worklist scheme
   int hyst_late_grid = 0;              // diagnostics (HC_HYST_LATE_GRID): workgroups of the hysteresis launches >= 1
+  int hyst_list_floor = 2048;          // smallest grid of a list launch (HC_HYST_LIST_FLOOR)
   int hyst_obs[3] = { 0, 0, 0 };       // hysteresis launches the last runs needed with base_waves << i waves per workgroup (0: not seen)
   int hyst_obs_base = 0, hyst_obs_rows = 0;  // the base shape those observations belong to
   bool split_set = false;  // HC_OPT_FRONT_SPLIT was set by the caller
@@ -472,7 +473,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
     // a run, launch_hyst's schedule by the tile count
     hp.late_grid = c->hyst_late_grid > 0 ? c->hyst_late_grid : 0;
     if (mixed_from > 0) hp.lists = k < mixed_from ? 0 : k == mixed_from ? 2 : 1;
-    if (hp.lists == 1 && !hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>(2048, 2 * (size_t)c->wl_prev[k] + 256));
+    if (hp.lists == 1 && !hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>((size_t)c->hyst_list_floor, 2 * (size_t)c->wl_prev[k] + 256));
     // diagnostics cost ~3 same-address atomics per wave (hundreds of microseconds per launch): opt-in only
     hp.stats = c->hyst_diag ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
     HIPCK(launch_hyst(hp, st));
@@ -832,6 +833,7 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   c->stream = c->own_stream;
   c->hyst_diag = getenv("HC_HYST_DIAG") != nullptr;
   if (const char *e = getenv("HC_HYST_LATE_GRID")) c->hyst_late_grid = std::max(-1, atoi(e));  // tests: tiny grids exercise the hand-on of worklist entries
+  if (const char *e = getenv("HC_HYST_LIST_FLOOR")) c->hyst_list_floor = std::max(1, atoi(e));
   if (const char *e = getenv("HC_HYST_GEOM")) {
     int tr = 0, wv = 0;
     if (sscanf(e, "%dx%d", &tr, &wv) == 2) c->hyst_geom = tr * 100 + wv;
