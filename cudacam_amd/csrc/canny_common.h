@@ -110,6 +110,10 @@ int front8_half_strips(int W);
 hipError_t launch_blur(const FrontParams &p, hipStream_t s);
 hipError_t launch_nms(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);
+// the first `rounds` launches of the workgroup-per-tile form as ONE launch with device-wide barriers between the rounds
+// (small runs: at most HYST_LOOP_MAX_TILES tiles); bar: two zeroed words (arrival counter, abort flag)
+constexpr int HYST_LOOP_MAX_TILES = 128;
+hipError_t launch_hyst_loop(const HystParams &p, int rounds, u32 *bar, hipStream_t s);
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
 // pitched device-to-device copy of n frames (any alignment on either side); rows, n <= 65535
 hipError_t launch_copy_rows(void *dst, size_t dpitch, size_t dfs, const void *src, size_t spitch, size_t sfs, size_t row_bytes, int rows, int n, hipStream_t s);

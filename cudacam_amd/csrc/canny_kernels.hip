@@ -2058,6 +2058,71 @@ __global__ __launch_bounds__(WAVES * 64) void k_hyst(const HystParams p)
   }
 }
 
+// ---- one launch for the whole hysteresis of a small run -------------------------------------------------------------
+// A run of a few frames (the reference's one-frame-per-call pattern and the small pipelined batches) has at most a few
+// dozen workgroup tiles, all resident at once, and its K dependent launches are K host calls and K trips through the
+// command processor for kernels that mostly find nothing to do.  k_hyst_loop runs the same rounds -- hyst_tile in its
+// workgroup-per-tile form, round `it` exactly what launch `it` would have been -- inside ONE launch, separated by a
+// device-wide barrier: every workgroup releases its stores (the XCDs' L2s are not coherent with each other: agent-scope
+// release = write-back, acquire = invalidate), arrives at a counter in device memory, waits for the others, acquires.
+// The flag word of a round tells all workgroups alike whether another round is needed.
+// Every wait is bounded: a workgroup that does not see the others arrive within ~4 ms (they are not resident -- another
+// process fills the device) raises the abort word, marks the run as not converged and leaves; so do the others when
+// they see it.  The host then continues the run with ordinary launches (finish_slot), as after any run whose queued
+// launches were too few.  The grid never waits for a workgroup that cannot come.
+static __device__ __forceinline__ bool grid_barrier(u32 *bar, u32 target)
+{
+  __shared__ u32 ok;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_fetch_add(&bar[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32 good = 1;
+    for (u32 spin = 0;; ++spin) {
+      if (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+      if (spin > 4000u || __hip_atomic_load(&bar[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+        __hip_atomic_store(&bar[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        good = 0;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    ok = good;
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return ok != 0;
+}
+
+template <int TR, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void k_hyst_loop(const HystParams p0, int rounds, u32 *bar)
+{
+  __builtin_amdgcn_s_setprio(3);
+  HystParams p = p0;
+  for (int it = 0; it < rounds; ++it) {
+    p.iter = it;
+    hyst_tile<1, TR, WAVES, false, 0>(p, (int)blockIdx.x, false, false, false);
+    if (it + 1 == rounds) return;  // (the host reads this round's flag: set = not converged, finish_slot continues)
+    if (!grid_barrier(bar, gridDim.x * (u32)(it + 1))) {
+      if (threadIdx.x == 0) atomicOr(&p.flags[rounds - 1], 1u);
+      return;
+    }
+    if (__hip_atomic_load(&p.flags[it], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;  // no tile boundary changed: the fixpoint (the same answer in every workgroup)
+  }
+}
+
+// rounds <= MAX launches of the workgroup-per-tile form in one launch; the caller guarantees one column panel, at most
+// HYST_LOOP_MAX_TILES tiles (resident together, with room for the loops of the other runs in flight) and bar[0..1] == 0
+hipError_t launch_hyst_loop(const HystParams &p, int rounds, u32 *bar, hipStream_t s)
+{
+  const size_t tiles = (size_t)p.nframes * p.nrtiles;
+  if (p.npanels != 1 || p.RD != 64 || tiles == 0 || tiles > (size_t)HYST_LOOP_MAX_TILES || rounds < 1 || !bar || !p.wl_reason || p.wl_stride < tiles) return hipErrorInvalidValue;
+  if (p.tile_rows == 16 && p.waves == 8) hipLaunchKernelGGL((k_hyst_loop<16, 8>), dim3((unsigned)tiles), dim3(512), 0, s, p, rounds, bar);
+  else if (p.tile_rows == 32 && p.waves == 2) hipLaunchKernelGGL((k_hyst_loop<32, 2>), dim3((unsigned)tiles), dim3(128), 0, s, p, rounds, bar);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t launch_hyst(const HystParams &p, hipStream_t s)
 {
   const HystGeom g = { 1, p.tile_rows, p.waves };

@@ -36,7 +36,7 @@ constexpr int FLAG_WORDS = MAX_HYST_LAUNCHES * 4;  // [0 .. MAX) launch flags, t
 // d_flags continues with what must also be zero when a run starts (one memset): the worklist counts of the hysteresis
 // launches, then the per-tile reason words of both launch parities (HystParams::wl_count / wl_reason)
 constexpr int WL_COUNT_WORDS = 128;
-static_assert(WL_COUNT_WORDS >= MAX_HYST_LAUNCHES + 1, "a count per launch and one beyond the last");
+static_assert(WL_COUNT_WORDS >= MAX_HYST_LAUNCHES + 1 + 2, "a count per launch, one beyond the last, and the two words of k_hyst_loop's barrier");
 
 // Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's hysteresis (pipelined
 // mode); the plain mode only uses slot 0.  (Three were measured on big batches: run i+1 then no longer waits for the
@@ -90,6 +90,7 @@ struct hc_ctx {
   bool hyst_lists_last = false;        // the last run used the worklist scheme
   int hyst_late_grid = 0;              // diagnostics (HC_HYST_LATE_GRID): workgroups of the hysteresis launches >= 1
   int hyst_list_floor = 2048;          // smallest grid of a list launch (HC_HYST_LIST_FLOOR)
+  bool hyst_loop = true;               // small runs: one looping hysteresis launch (HC_HYST_LOOP=0 turns it off)
   int hyst_obs[3] = { 0, 0, 0 };       // hysteresis launches the last runs needed with base_waves << i waves per workgroup (0: not seen)
   int hyst_obs_base = 0, hyst_obs_rows = 0;  // the base shape those observations belong to
   bool split_set = false;  // HC_OPT_FRONT_SPLIT was set by the caller
@@ -465,8 +466,22 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // few long edges through the frame (launch 2 still starts every tile, and writes the first list): 1080p grey 394 -> 405 k
   // frames/s, 256 frames per run 307 -> 317 k; with the lists from launch 1 on: 400 k, from launch 4: 404 k.  (The list
   // streams above keep their lists from launch 1: BGR 259 against 252 k, 8K x 3 8.76 against 8.64 k; 4K would gain 2 %.)
-  const int mixed_from = (!hp.lists && !c->hyst_late_grid && small_tiles) ? 2 : 0;
-  for (int k = 0; k < K; ++k) {
+  int mixed_from = (!hp.lists && !c->hyst_late_grid && small_tiles) ? 2 : 0;
+  // A small run (a few frames): all K rounds in one launch, device-wide barriers between them (k_hyst_loop) -- K host
+  // calls and K trips through the command processor fewer per run; a run it cannot finish (its workgroups not resident
+  // together, or more rounds needed than queued) is continued by finish_slot like any other.
+  // (not beside other runs: in the pipelined small batches the rounds' barriers -- ~10 us each, with the waiting workgroups
+  // resident -- cost more than the launches they replace: 8 frames per run 0.147 against 0.117 ms per call; one frame per
+  // call, the reference's pattern: 0.150 against 0.168 ms)
+  const bool loop = c->hyst_loop && !small_tiles && !hp.lists && !c->hyst_late_grid && !c->hyst_diag && hp.npanels == 1 && c->RD == 64 && hp.wl_stride <= (size_t)HYST_LOOP_MAX_TILES
+                    && ((hp.tile_rows == 16 && hp.waves == 8) || (hp.tile_rows == 32 && hp.waves == 2));
+  if (loop) {
+    mixed_from = 0;
+    hp.iter = 0; hp.late_grid = 0; hp.stats = nullptr;
+    HIPCK(launch_hyst_loop(hp, K, s.d_flags + FLAG_WORDS + WL_COUNT_WORDS - 2, st));  // (the last two count words: unused by this form, zeroed with the flags)
+    hp.iter = K - 1;
+  }
+  for (int k = loop ? K : 0; k < K; ++k) {
     hp.iter = k;
     // worklist scheme, launches >= 1: a workgroup per list entry.  Grid: twice what the last run of this shape listed for
     // the launch (entries beyond the grid wait a launch: a dense frame would need several launches more); without such
@@ -833,6 +848,7 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   c->stream = c->own_stream;
   c->hyst_diag = getenv("HC_HYST_DIAG") != nullptr;
   if (const char *e = getenv("HC_HYST_LATE_GRID")) c->hyst_late_grid = std::max(-1, atoi(e));  // tests: tiny grids exercise the hand-on of worklist entries
+  if (const char *e = getenv("HC_HYST_LOOP")) c->hyst_loop = atoi(e) != 0;
   if (const char *e = getenv("HC_HYST_LIST_FLOOR")) c->hyst_list_floor = std::max(1, atoi(e));
   if (const char *e = getenv("HC_HYST_GEOM")) {
     int tr = 0, wv = 0;

@@ -171,11 +171,12 @@ def test_mode_o_three_channel_device_buffers(oracle):
     _diff(d_out.cpu().numpy(), oracle.canny_o(img, 50, 150), "mode O 3-channel, unaligned device buffers")
 
 
-@pytest.mark.parametrize("w,h,nb,form", [(640, 480, 400, 1), (640, 480, 300, 2), (200, 120, 4200, 1), (744, 60, 2300, 1), (745, 60, 2300, 2), (496, 60, 3400, 2), (1280, 90, 900, 2)])
+@pytest.mark.parametrize("w,h,nb,form", [(640, 480, 400, 4), (640, 480, 3, 4), (640, 480, 1, 2), (200, 120, 4200, 4), (744, 60, 2300, 2), (745, 60, 2300, 2), (496, 60, 3400, 2), (1000, 60, 2300, 4), (1280, 90, 900, 2)])
 def test_default_form_by_width(oracle, w, h, nb, form):
-    """While HC_OPT_FRONT_SPLIT is unset the library picks the front form by how well the width fills the strips: for big
-    batches (0.1 G pixels per run or more) the 4-px pair (248-column strips) up to 248 and for 497..744 columns, k_front8
-    (496-column strips) otherwise and for small batches -- the same blur, bit planes and edges either way."""
+    """The library picks k_front8's form by how many waves a run needs: the half-strip form (two 240-column half-waves per
+    wave, units paired across strips and frames: form 4) whenever that is fewer than with 496-column strips (form 2) --
+    640 columns: 1.5 waves per frame instead of 2 -- and never one of the round-1 4-px kernels (forms 1 / 0: round 2 sent
+    narrow big batches there).  The same blur, bit planes and edges either way."""
     uniq = np.stack([synth.natural(w, h, 5 + w + k) for k in range(4)])
     frames = np.tile(uniq, ((nb + 3) // 4, 1, 1))[:nb]
     with api.Context(w, h, 1, nb) as ctx:
