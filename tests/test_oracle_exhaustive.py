@@ -71,3 +71,15 @@ def test_threshold_bands_all_S():
         a0, a1, a2 = 4 * (T + 1) ** 2, 4 * (257 + T) ** 2, 4 * (513 + T) ** 2
         band = ((S >= a0) & (S < B0)) | ((S >= a1) & (S < B1)) | (S >= a2)
         assert np.array_equal(band, val > T), T
+
+
+def test_quotient_by_24bit_multiply_all_sums():
+    """k_front8's exact quotient (round 3): floor(S / 159) = (S * 105518) >> 24 for every reachable S = sum K*x <= 40545, the
+    product stays below 2^32 (one v_mul_u32_u24 per pixel), and its bits 16..23 -- the "fraction byte" -- are all zero exactly
+    when S % 159 == 0, the only sums for which the reference's float chain (cannyEdgeD.cu:102-115) can fall below the integer
+    quotient (those pixels get the literal chain)."""
+    S = np.arange(0, 159 * 255 + 1, dtype=np.uint64)
+    P = S * np.uint64(105518)
+    assert int(P.max()) < 2 ** 32
+    assert np.array_equal(P >> np.uint64(24), S // np.uint64(159))
+    assert np.array_equal(((P >> np.uint64(16)) & np.uint64(255)) == 0, S % np.uint64(159) == 0)
