@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
     ap.add_argument("--out-buffers", type=int, default=0, help="pipelined mode: output buffers used in turn (a run into memory that an earlier, still unfinished run writes waits for that run); 0 = as many as the context keeps runs in flight: 2, or 4 for small batches")
     ap.add_argument("--front", default=None, choices=["front8", "split", "fused4"], help="front path (HC_OPT_FRONT_SPLIT): front8 = one kernel, 8 px per lane (default; Mode O: k_front8o); split = k_blur + k_nms; fused4 = the 4-px fused kernel (Mode O: both = k_front_o)")
+    ap.add_argument("--dense", default="auto", choices=["auto", "never", "always"], help="k_front8's dense path (HC_OPT_FRONT_DENSE): wave-wide NMS for windows full of candidates")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3], help="3: interleaved BGR input (grey conversion fused into the load)")
     ap.add_argument("--per-channel", action="store_true", help="with --channels 3: one edge map per channel (BASELINE configs[4])")
@@ -170,6 +171,8 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
 
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
+    if a.dense != "auto":
+        ctx.set_option(api.OPT_FRONT_DENSE, {"never": 0, "always": 1}[a.dense])
     if a.front is not None:   # (unset: the library's choice -- k_front8 / k_front8o, the 4-px pair for narrow frames)
         ctx.set_option(api.OPT_FRONT_SPLIT, {"front8": 2, "split": 1, "fused4": 0}[a.front])   # (Mode O: front8 = k_front8o, the others = the 4-px k_front_o)
     # the context keeps its own (non-blocking) stream: the inputs were produced before the synchronize below, and the

@@ -52,6 +52,9 @@ struct FrontParams {
   // own: STRONG plane bytes (dump), CANDIDATE plane bytes (dump_c), provisional map (dump_p).  Plain form: 2 KiB, 2 KiB,
   // W + 8 bytes.  HALF form: each + the byte offset of half-wave B's frame (3 * H * RD * 4 / 3 * prov_fs at most).
   uint8_t *dump, *dump_c, *dump_p;
+  // k_front8 / k_front8o: words the kernel zeroes before anything else (the run's hysteresis flags, worklist counts and
+  // reason words: one memset kernel and one host call fewer per run); null: nothing
+  u32 *zero_words; u32 zero_count;
   int half;        // k_front8: HALF form (two 240-column half-strips per wave, narrow frames); nstrips is unused then
   int nhalf;       // HALF form: half-strips per frame = ceil(W / 240); total_items = ceil(in_frames * nhalf / 2) * nchunks (* 3 per-channel)
   // k_front8: a window that follows one with more than dense_enter half-lanes above the low threshold takes the dense path

@@ -112,6 +112,8 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   // per lane and row are fetched from HBM once and served to the other two waves from the CU's L1 / the XCD's L2.
   // (Without the barrier the three drifted apart and the input was fetched about twice: 5.5 GB per 16 8K frames.)
   constexpr int WPB = IN == 2 ? 3 : F8_WPB;
+  // the flag words of this run's hysteresis (a few hundred to 140 k dwords), zeroed by the first workgroups on their way in
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < p.zero_count; i += gridDim.x * blockDim.x) p.zero_words[i] = 0u;
   int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPB + wib);
   if (item >= p.total_items) return;  // (per-channel: total_items is a multiple of 3, a workgroup leaves as a whole)
   int ch = 0;
@@ -732,6 +734,7 @@ __global__ __launch_bounds__(256) void k_front8o(const FrontParams p)
   const int wib = threadIdx.x >> 6;
   unsigned char *bring = smem + wib * F8O_WAVE_BYTES;  // source rows (columns outside the image zero)
   lds_u32 *nq = (lds_u32 *)(bring + F8_RING * F8_ROW_BYTES);
+  for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < p.zero_count; i += gridDim.x * blockDim.x) p.zero_words[i] = 0u;  // (as k_front8)
   const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
   if (item >= p.total_items) return;
   const int chunk = item % p.nchunks;

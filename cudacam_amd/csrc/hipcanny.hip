@@ -387,7 +387,8 @@ int finish_all(hc_ctx *c)
 }
 
 // bit planes of slot s -> fixpoint -> u8 image, queued on `st`
-int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t out_pitch, size_t out_fs, int n, bool small_tiles)
+// flags_zeroed: the front kernel of this run already zeroed `zeroed_words` words of s.d_flags (FrontParams::zero_words)
+int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t out_pitch, size_t out_fs, int n, bool small_tiles, size_t zeroed_words = 0)
 {
   HystParams hp{};
   hp.sbits = s.d_sbits; hp.cbits = s.d_cbits; hp.RD = c->RD; hp.H = c->H; hp.nframes = n; hp.flags = s.d_flags;
@@ -448,7 +449,8 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   hp.wl_count = s.d_flags + FLAG_WORDS;
   hp.wl_reason = s.d_flags + FLAG_WORDS + WL_COUNT_WORDS;
   hp.wl_list = s.d_wl_list;
-  HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * hp.wl_stride), st));
+  if (zeroed_words < FLAG_WORDS + WL_COUNT_WORDS + 2 * hp.wl_stride)
+    HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * hp.wl_stride), st));
   // Worklists or a workgroup per tile in every launch (k_hyst)?  Lists where the step follows the hysteresis chain:
   // frames wider than one panel -- unless they are dense (the last run visited more than 60 % of the tiles in launch 1:
   // noise; camera-like frames: a third; the front kernel, which bounds such streams, loses less to a hysteresis that is
@@ -661,14 +663,20 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.total_items_b = n_out * fp.nstrips * fp.nchunks_b;
 
     }
+    size_t zeroed_words = 0;
     if (f8) {  // strips of 496 columns, runs of 6 * windows - 4 rows
+      // the 8-px kernels zero the run's hysteresis flag words on their way in: every tile shape has at least 16 rows per tile
+      zeroed_words = FLAG_WORDS + WL_COUNT_WORDS + 2 * std::min(s.wl_cap, (size_t)n_out * ((size_t)(H + 15) / 16 + 1) * (size_t)((c->RD + 63) / 64));
+      fp.zero_words = s.d_flags; fp.zero_count = (u32)zeroed_words;
       fp.dump = c->d_dump; fp.dump_c = c->d_dump + 2048; fp.dump_p = c->d_dump + 4096;
       fp.zeros = c->d_dump + 16384;
       fp.nstrips = front8_strips(W);
-      // dense path of k_front8 (wave-wide NMS): enter above 320 half-lanes per window of 768, leave below 256 -- the batch
-      // scheme costs 27 + 41 + 3.6 e instructions per row for e queued half-lanes, the dense path ~260
-      fp.dense_enter = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : 320;
-      fp.dense_leave = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : 256;
+      // dense path of k_front8 (wave-wide NMS): enter above 512 half-lanes per window of 768, leave below 384.  (The batch
+      // scheme costs 27 + 41 + 3.6 e instructions per row for e queued half-lanes, the dense path ~260: break-even near
+      // 320 per window -- but the zero padding makes the first two rows of every frame candidates across the whole
+      // width, and with 320 the window after them went dense on every natural frame: +1.2 % on the benchmark's frames.)
+      fp.dense_enter = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : 512;
+      fp.dense_leave = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : 384;
       long waves_per_chunk = (long)n_out * fp.nstrips;
       if (c->mode == HC_MODE_R && c->dump_region && c->half_mode != 0) {
         // HALF form (narrow frames): the (frame, 240-column half-strip) units of a run of rows are dealt to half-waves in
@@ -751,7 +759,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       HIPCK(hipEventRecord(s.ev_front, sf));
       HIPCK(hipStreamWaitEvent(sh, s.ev_front, 0));
     }
-    if (int rc = queue_hyst_expand(c, s, sh, dst, dp, dfs, n_out, piped)) return rc;
+    if (int rc = queue_hyst_expand(c, s, sh, dst, dp, dfs, n_out, piped, zeroed_words)) return rc;
   } else if (stage > HC_STAGE_MONO) {
     if (int rc = ensure_stage_scratch(c)) return rc;
     const size_t bp = c->out_pitch, bfs = c->out_fs;  // scratch planes share the output geometry

@@ -216,8 +216,8 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * allow it (parity tests).  hc_last_run_info reports it as front form 4.
  *
  * HC_OPT_FRONT_DENSE (default -1 = automatic, Mode R): k_front8's dense path -- a window of 6 rows that follows one in
- * which more than 320 of the wave's 768 half-lanes passed the low threshold (noise, texture) is processed by wave-wide
- * non-maximum suppression in registers instead of the queue and its batches, until a window counts fewer than 256.
+ * which more than 512 of the wave's 768 half-lanes passed the low threshold (noise, texture) is processed by wave-wide
+ * non-maximum suppression in registers instead of the queue and its batches, until a window counts fewer than 384.
  * 0 = never, 1 = every window (parity tests).  Same results either way.
  *
  * HC_OPT_COPY_STREAMS (default 0): host pipelines of several contexts (cvp::io::FrameStreamer).  1 = hc_upload and

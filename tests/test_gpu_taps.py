@@ -184,7 +184,7 @@ def test_default_form_by_width(oracle, w, h, nb, form):
         got = ctx.process(frames)
         assert ctx.last_run_info()[2] == form
         tb, tt = ctx.debug_tap(api.TAP_BLUR, nb), ctx.debug_tap(api.TAP_THRESH, nb)
-        for k in (0, 1, 2, 3, nb - 1):
+        for k in sorted({0, 1, 2, 3, nb - 1} & set(range(nb))):
             blur, thr, edges = _want(oracle, frames[k], 10, 40)
             _diff(tb[k], blur, f"{w}x{h} frame {k}: blur")
             _diff(tt[k], thr, f"{w}x{h} frame {k}: bit planes")
