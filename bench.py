@@ -162,7 +162,9 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     # output batches used in turn, as a pipelined consumer would (run i's maps are read while run i+1 computes): as many
     # as the context keeps runs in flight (hc_pipeline_depth: 2, or 4 for small batches); with a single one the library
     # falls back to the non-provisional expand to keep run i+1's map intact
-    ctx = api.Context(W, H, C, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local)
+    # (--front split / fused4 in mode R: the round-1 kernels live in the test library, cudacam_amd/libhipcanny_legacy.so)
+    ctx = api.Context(W, H, C, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local,
+                      front_split=None if a.front is None else {"front8": 2, "split": 1, "fused4": 0}[a.front])
     ctx.set_option(api.OPT_PIPELINE, 0 if a.no_pipeline else 1)
     if a.per_channel:
         ctx.set_option(api.OPT_PER_CHANNEL, 1)
@@ -173,8 +175,6 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     ctx.set_tuning(a.chunk, a.hyst_launches)
     if a.dense != "auto":
         ctx.set_option(api.OPT_FRONT_DENSE, {"never": 0, "always": 1}[a.dense])
-    if a.front is not None:   # (unset: the library's choice -- k_front8 / k_front8o, the 4-px pair for narrow frames)
-        ctx.set_option(api.OPT_FRONT_SPLIT, {"front8": 2, "split": 1, "fused4": 0}[a.front])   # (Mode O: front8 = k_front8o, the others = the 4-px k_front_o)
     # the context keeps its own (non-blocking) stream: the inputs were produced before the synchronize below, and the
     # timed region is bracketed by hc_sync + torch.cuda.synchronize, so no ordering with torch's stream is needed
 

@@ -60,6 +60,8 @@ ABI_SYMBOLS = [
 ]
 
 _lib = None
+_lib_legacy = None
+LEGACY_LIB_PATH = os.path.join(_HERE, "libhipcanny_legacy.so")
 
 
 class HipCannyError(RuntimeError):
@@ -82,15 +84,20 @@ def preload_hip_runtime():
     return None
 
 
-def load_library():
-    """Loads libhipcanny.so (fails loudly when it has not been built)."""
-    global _lib
-    if _lib is not None:
+def load_library(legacy=False):
+    """Loads libhipcanny.so (fails loudly when it has not been built).  legacy: libhipcanny_legacy.so instead -- the same
+    sources plus the round-1 front kernels of Mode R (HC_OPT_FRONT_SPLIT 1 / 0), which the product library no longer
+    contains; parity tests run every case through them as independent implementations."""
+    global _lib, _lib_legacy
+    if legacy and _lib_legacy is not None:
+        return _lib_legacy
+    if not legacy and _lib is not None:
         return _lib
     preload_hip_runtime()
-    if not os.path.exists(LIB_PATH):
-        raise HipCannyError(f"{LIB_PATH} is missing: run `python -m cudacam_amd.build` (hipcc, gfx950). There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    path = LEGACY_LIB_PATH if legacy else LIB_PATH
+    if not os.path.exists(path):
+        raise HipCannyError(f"{path} is missing: run `python -m cudacam_amd.build` (hipcc, gfx950). There is no CPU fallback.")
+    L = C.CDLL(path)
     vp, sz, i = C.c_void_p, C.c_size_t, C.c_int
     L.hc_create.restype = vp
     L.hc_create.argtypes = [i, i, i, i, i, i]
@@ -132,12 +139,20 @@ def load_library():
     L.hc_version.restype = C.c_char_p
     for name in ABI_SYMBOLS:
         getattr(L, name)
-    _lib = L
+    if legacy:
+        _lib_legacy = L
+    else:
+        _lib = L
     return L
 
 
 def last_error():
-    return load_library().hc_last_error().decode()
+    msg = load_library().hc_last_error().decode()
+    if _lib_legacy is not None:   # (a context of the test library keeps its error text there)
+        other = _lib_legacy.hc_last_error().decode()
+        if other and other != msg:
+            msg = (msg + " | " if msg else "") + other
+    return msg
 
 
 def _ck(rc):
@@ -148,12 +163,17 @@ def _ck(rc):
 class Context:
     """Thin RAII wrapper of hc_ctx (one device, one stream)."""
 
-    def __init__(self, width, height, channels=1, max_batch=1, mode=MODE_R, device=0):
-        self.lib = load_library()
+    def __init__(self, width, height, channels=1, max_batch=1, mode=MODE_R, device=0, front_split=None):
+        """front_split: HC_OPT_FRONT_SPLIT for the context's whole life (None: the library's default, k_front8 / k_front8o).
+        The round-1 front kernels of Mode R (1: k_blur + k_nms, 0: the 4-px k_front) are not part of the product library:
+        such a context is created in libhipcanny_legacy.so (parity tests, bench.py --front split / fused4)."""
+        self.lib = load_library(legacy=front_split in (0, 1) and int(mode) == MODE_R)
         self.w, self.h, self.c, self.max_batch = int(width), int(height), int(channels), int(max_batch)
         self.handle = self.lib.hc_create(int(device), self.w, self.h, self.c, self.max_batch, int(mode))
         if not self.handle:
             raise HipCannyError(f"hc_create failed: {last_error()}")
+        if front_split is not None:
+            self.set_option(OPT_FRONT_SPLIT, front_split)
 
     def close(self):
         if getattr(self, "handle", None):

@@ -10,16 +10,20 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libhipcanny.so")
+# the same sources + the round-1 front kernels of Mode R (HC_OPT_FRONT_SPLIT 1 / 0): independent implementations for the
+# parity tests, not part of the product
+LIB_LEGACY = os.path.join(HERE, "libhipcanny_legacy.so")
 SOURCES = ["canny_kernels.hip", "front8.hip", "hipcanny.hip"]
-DEPS = SOURCES + ["canny_common.h", "canny_device.h", os.path.join("..", "..", "include", "hipcanny.h")]
+LEGACY_SOURCES = SOURCES + ["legacy_front.hip"]
+DEPS = LEGACY_SOURCES + ["canny_common.h", "canny_device.h", os.path.join("..", "..", "include", "hipcanny.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 
-def stale():
-    if not os.path.exists(LIB):
+def stale(lib=LIB):
+    if not os.path.exists(lib):
         return True
-    t = os.path.getmtime(LIB)
+    t = os.path.getmtime(lib)
     return any(os.path.getmtime(os.path.join(CSRC, d)) > t for d in DEPS)
 
 
@@ -33,5 +37,17 @@ def build(force=False, verbose=False):
     return LIB
 
 
+def build_legacy(force=False, verbose=False):
+    """libhipcanny_legacy.so: the product's sources + legacy_front.hip (-DHC_LEGACY_FRONT); test infrastructure."""
+    if not force and not stale(LIB_LEGACY):
+        return LIB_LEGACY
+    cmd = [HIPCC] + FLAGS + ["-DHC_LEGACY_FRONT"] + [os.path.join(CSRC, s) for s in LEGACY_SOURCES] + ["-o", LIB_LEGACY]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_LEGACY
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_legacy(force="--force" in sys.argv, verbose=True))

@@ -102,16 +102,20 @@ struct PackParams {  // tri-state u8 map (0/128/255) -> bit planes
 // ---- host-callable launchers (defined in canny_kernels.hip) -----------------------------------
 hipError_t launch_selftest(u32 *d_result, hipStream_t s);
 hipError_t check_gauss_coeffs(const float gk[25]);
-hipError_t launch_front(const FrontParams &p, hipStream_t s);
 hipError_t launch_front_o(const FrontParams &p, hipStream_t s);
+#ifdef HC_LEGACY_FRONT  // legacy_front.hip: the round-1 front kernels of Mode R, built into libhipcanny_legacy.so only (parity tests)
+hipError_t launch_front(const FrontParams &p, hipStream_t s);
+hipError_t launch_blur(const FrontParams &p, hipStream_t s);
+hipError_t launch_nms(const FrontParams &p, hipStream_t s);
+size_t front_lds_bytes();
+int front_run_rows(int subchunks);
+#endif
 // front8.hip: the whole front path as one kernel, 8 px per lane (strips of 496 columns, runs of 6 * windows - 4 rows)
 hipError_t launch_front8(const FrontParams &p, hipStream_t s);
 hipError_t launch_front8o(const FrontParams &p, hipStream_t s);  // Mode O on the same skeleton (one-channel sources)
 int front8_run_rows(int windows);
 int front8_strips(int W);
 int front8_half_strips(int W);
-hipError_t launch_blur(const FrontParams &p, hipStream_t s);
-hipError_t launch_nms(const FrontParams &p, hipStream_t s);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 // the first `rounds` launches of the workgroup-per-tile form as ONE launch with device-wide barriers between the rounds
 // (small runs: at most HYST_LOOP_MAX_TILES tiles); bar: two zeroed words (arrival counter, abort flag)
@@ -120,8 +124,6 @@ hipError_t launch_hyst_loop(const HystParams &p, int rounds, u32 *bar, hipStream
 hipError_t launch_pack(const PackParams &p, hipStream_t s);
 // pitched device-to-device copy of n frames (any alignment on either side); rows, n <= 65535
 hipError_t launch_copy_rows(void *dst, size_t dpitch, size_t dfs, const void *src, size_t spitch, size_t sfs, size_t row_bytes, int rows, int n, hipStream_t s);
-size_t front_lds_bytes();
-int front_run_rows(int subchunks);
 void hyst_tile_geometry(int geom, bool beside_front, long frames_x_rows, int H, int *tile_rows, int *waves);
 
 // plain per-stage kernels (exact, unfused): the `finalStage` taps MONO..THRESH of CannyEdge::run

@@ -21,6 +21,35 @@ struct GaussLiterals {
 };
 constexpr GaussLiterals GKC{};
 
+// literal reference chain for one pixel (cannyEdgeD.cu:102-115): 25 fused multiply-adds from 0.0f in
+// r-major / c-minor order, truncation.  Only used for the rare undecidable pixels.
+// IN: how a pixel is read -- 0 mono plane, 1 BGR -> grey (stage 0 fused), 2 channel `ch` of interleaved 3-channel data
+template <int IN = 0>
+static __device__ __forceinline__ u32 gauss_chain_px(const uint8_t *frame, size_t pitch, int W, int H, int row, int col, int ch = 0)
+{
+  // the coefficients are literals of the instruction stream (GKC): as __constant__ loads they were
+  // hoisted to the kernel entry and pinned 25 SGPRs across the hot loops
+  float f = 0.0f;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const int rr = row - 2 + r;
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const int cc = col - 2 + c;
+      float px = 0.0f;
+      if (rr >= 0 && rr < H && cc >= 0 && cc < W) {
+        if (IN == 1) {  // stage 0 on the fly: (b*7 + g*38 + r*19) >> 6 (cannyEdgeD.cu:17-19,67)
+          const uint8_t *q = frame + (size_t)rr * pitch + 3 * (size_t)cc;
+          px = (float)((q[0] * 7 + q[1] * 38 + q[2] * 19) >> 6);
+        } else if (IN == 2) px = (float)frame[(size_t)rr * pitch + 3 * (size_t)cc + ch];
+        else px = (float)frame[(size_t)rr * pitch + cc];
+      }
+      f = __builtin_fmaf(GKC.v[r * 5 + c], px, f);
+    }
+  }
+  return (u32)(int)f;
+}
+
 // ---- cross-lane and packed helpers -------------------------------------------------------------
 // value held by lane-1 (0 in lane 0) / lane+1 (0 in lane 63): DPP wave shifts, no LDS involved
 static __device__ __forceinline__ u32 from_lane_below(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xF, 0xF, true); }

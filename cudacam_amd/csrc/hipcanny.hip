@@ -608,14 +608,17 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     fp.in = mono; fp.bgr = c->per_channel ? 2 : fuse_bgr ? 1 : 0; fp.in_pitch = mp; fp.in_frame_stride = mfs; fp.sbits = s.d_sbits; fp.cbits = s.d_cbits; fp.RD = c->RD; fp.W = W; fp.H = H;
     // Mode R, fused kernel: a wave marches through `subchunks` sub-chunks of 24 blur rows (run of 24*m - 4
     // output rows).  Longer runs amortise the 8-row warm-up; shorter runs give more work items (small batches).
+    fp.nstrips = c->nstrips; fp.nframes = n_out;
+#ifdef HC_LEGACY_FRONT
     int m = c->chunk ? (c->chunk + 4 + 23) / 24 : 0;
     if (m == 0) {
       m = 3;
       while (m > 1 && (long)n_out * c->nstrips * ((H + front_run_rows(m) - 1) / front_run_rows(m)) < 24576) --m;
     }
     fp.subchunks = m; fp.run_rows = front_run_rows(m);
-    fp.nstrips = c->nstrips; fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows; fp.nframes = n_out;
+    fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
     fp.total_items = n_out * fp.nstrips * fp.nchunks;
+#endif
     // Mode R front path: k_front8 reads whole 8-pixel groups (8 or 24 bytes per lane and row), the 4-px kernels 4-pixel groups
     const bool can8 = sp >= round_up((size_t)W, 8) * (size_t)(fuse_bgr || c->per_channel ? 3 : 1);
     // Mode O: k_front8o (form 3) for one-channel sources, the 4-px k_front_o (form -1) for 3-channel ones, for rows that
@@ -651,6 +654,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       if (int rc = ensure_debug_buffers(c)) return rc;
       if (!split) { fp.dbg_blur = c->dbg_blur; fp.dbg_pitch = (u32)c->out_pitch; fp.dbg_fs = c->out_fs; }  // out_pitch: the width if that is a multiple of 16, else padded to 256
     }
+#ifdef HC_LEGACY_FRONT
     if (split) {  // k_blur + k_nms through the blur plane
       if (int rc = ensure_blur_plane(c)) return rc;
       fp.blur = c->d_bplane; fp.blur_frame_stride = c->bplane_fs;
@@ -663,6 +667,9 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.total_items_b = n_out * fp.nstrips * fp.nchunks_b;
 
     }
+#else
+    if (!f8 && c->mode == HC_MODE_R) return fail(HC_E_ARG, "this library is built without the round-1 front kernels (HC_OPT_FRONT_SPLIT 1 / 0: libhipcanny_legacy.so)");
+#endif
     size_t zeroed_words = 0;
     if (f8) {  // strips of 496 columns, runs of 6 * windows - 4 rows
       // the 8-px kernels zero the run's hysteresis flag words on their way in: every tile shape has at least 16 rows per tile
@@ -736,14 +743,19 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       band_thresholds(c->high, c->nms_saturate != 0, fp.a_hi);
       fp.wrap_limit = c->nms_saturate ? 0xFFFFFFFFu : 262144u;
       const unsigned b_mono = fuse_bgr ? B_MONO : 0u;  // stage 0 fused into the blur's load (per-channel mode has no grey stage)
+#ifdef HC_LEGACY_FRONT
       if (split) {
         HIPCK(launch_blur(fp, sf));
         HIPCK(mark(sf, b_mono | B_GAUSS, hc_ctx::K_FRONT_A));
         HIPCK(launch_nms(fp, sf));
         HIPCK(mark(sf, B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
-      } else {
-        if (f8) HIPCK(launch_front8(fp, sf));
-        else HIPCK(launch_front(fp, sf));
+      } else if (!f8) {
+        HIPCK(launch_front(fp, sf));
+        HIPCK(mark(sf, b_mono | B_GAUSS | B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
+      } else
+#endif
+      {
+        HIPCK(launch_front8(fp, sf));
         HIPCK(mark(sf, b_mono | B_GAUSS | B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
       }
     }
@@ -808,7 +820,11 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
 extern "C" {
 
 const char *hc_last_error(void) { return g_err.c_str(); }
-const char *hc_version(void) { return "hipcanny 0.3 (gfx950)"; }
+#ifdef HC_LEGACY_FRONT
+const char *hc_version(void) { return "hipcanny 0.4 (gfx950) + round-1 front kernels (test build)"; }
+#else
+const char *hc_version(void) { return "hipcanny 0.4 (gfx950)"; }
+#endif
 
 void *hc_host_alloc(size_t bytes)
 {
@@ -969,6 +985,10 @@ int hc_set_option(hc_ctx *c, int option, int value)
     }
   } else if (option == HC_OPT_FRONT_SPLIT) {
     if (value < 0 || value > 2) return fail(HC_E_ARG, "HC_OPT_FRONT_SPLIT: 0 (k_front), 1 (k_blur + k_nms) or 2 (k_front8)");
+#ifndef HC_LEGACY_FRONT
+    if (value != 2 && c->mode == HC_MODE_R)
+      return fail(HC_E_ARG, "HC_OPT_FRONT_SPLIT 1 / 0: the round-1 front kernels are not part of this library (parity tests load libhipcanny_legacy.so)");
+#endif
     c->split = value;
     c->split_set = true;  // the caller's choice: no automatic switch to the 4-px pair for narrow frames
   } else if (option == HC_OPT_COPY_STREAMS) {

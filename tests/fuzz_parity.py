@@ -52,7 +52,7 @@ for i in range(cases):
             want = np.stack([O.canny_r(np.ascontiguousarray(f[:, :, c]), low, high, saturate=bool(opts["sat"])) for f in frames for c in range(3)])
         else:
             want = np.stack([O.canny_r(f, low, high, saturate=bool(opts["sat"])) for f in frames])
-    with api.Context(w, h, ch, nb, api.MODE_R if mode == "R" else api.MODE_O) as ctx:
+    with api.Context(w, h, ch, nb, api.MODE_R if mode == "R" else api.MODE_O, front_split=opts["split"]) as ctx:   # (split 1 / 0 in mode R: the test library)
         if ch == 3 and opts["pc"]:
             ctx.set_option(api.OPT_PER_CHANNEL, 1)
         ctx.set_thresholds(low, high)
@@ -86,7 +86,7 @@ for i in range(cases):
         seq = [np.stack([np.roll(f, 7 * (r + 1), axis=0) for f in frames]) for r in range(3)]
         d_in = [dev(fr) for fr in seq]
         d_o = [torch.full((nb, h, pitch), 3, dtype=torch.uint8, device="cuda") for _ in range(2)]
-        with api.Context(w, h, 1, nb, api.MODE_R if mode == "R" else api.MODE_O) as ctx:
+        with api.Context(w, h, 1, nb, api.MODE_R if mode == "R" else api.MODE_O, front_split=opts["split"]) as ctx:
             ctx.set_thresholds(low, high)
             if mode == "R":
                 ctx.set_option(api.OPT_NMS_SATURATE, opts["sat"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)

@@ -78,3 +78,17 @@ def test_timer_manager():
     tm.addTime("t", 4.0)
     assert tm.getAverageTime("t") == 3.0
     assert tm.getAverageTime("missing") == 0.0
+
+
+def test_round1_front_kernels_are_not_in_the_product_library(lib):
+    """The round-1 front kernels of Mode R (k_front, k_blur, k_nms: legacy_front.hip) are test infrastructure since round 3:
+    the product library does not contain them; libhipcanny_legacy.so (the same sources + those kernels) does."""
+    product = open(api.LIB_PATH, "rb").read()
+    legacy = open(build.build_legacy(), "rb").read()
+    for name in (b"_ZN2hc6k_blurILi", b"_ZN2hc5k_nmsE", b"_ZN2hc7k_frontILi"):   # the kernels' mangled names
+        assert name not in product, name
+        assert name in legacy, name
+    for name in (b"k_front8", b"k_front8o", b"k_front_o", b"k_hyst"):
+        assert name in product, name
+    assert b"test build" not in lib.hc_version()
+    assert b"test build" in api.load_library(legacy=True).hc_version()

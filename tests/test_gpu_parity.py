@@ -62,8 +62,7 @@ def test_chunk_invariance(oracle, chunk, split):
     """Rows per work item (and the one-kernel / two-kernel form of the front path) never change the result."""
     img = synth.natural(700, 333, 11)
     want = oracle.canny_r(img, 10, 40)
-    with api.Context(700, 333, 1, 1) as ctx:
-        ctx.set_option(api.OPT_FRONT_SPLIT, split)
+    with api.Context(700, 333, 1, 1, front_split=split) as ctx:
         ctx.set_tuning(chunk, 4)
         _diff(ctx.process(img)[0], want, f"chunk {chunk} split {split}")
 
@@ -118,13 +117,11 @@ def test_fused_front_kernel(oracle, kind):
     img = {"noise": lambda: synth.noise(517, 203, 3), "flat": lambda: synth.flat(517, 203, 100),
            "steps": lambda: synth.steps(517, 203, 90), "natural": lambda: synth.natural(517, 203, 3)}[kind]()
     want = oracle.canny_r(img, 10, 40)
-    with api.Context(517, 203, 1, 1) as ctx:
-        ctx.set_option(api.OPT_FRONT_SPLIT, 0)
+    with api.Context(517, 203, 1, 1, front_split=0) as ctx:
         _diff(ctx.process(img)[0], want, f"fused {kind}")
     rng = np.random.default_rng(17)
     bgr = rng.integers(0, 256, (90, 260, 3), dtype=np.uint8)
-    with api.Context(260, 90, 3, 1) as ctx:
-        ctx.set_option(api.OPT_FRONT_SPLIT, 0)
+    with api.Context(260, 90, 3, 1, front_split=0) as ctx:
         _diff(ctx.process(bgr)[0], oracle.canny_r(bgr, 10, 40), "fused bgr")
 
 
@@ -478,7 +475,7 @@ def test_context_reuse_sequences(oracle):
     w, h, nb = 700, 300, 4
     frames = np.stack([synth.natural(w, h, 60 + f) for f in range(nb)])
     noise = np.stack([synth.noise(w, h, 80 + f) for f in range(nb)])
-    with api.Context(w, h, 1, nb) as ctx:
+    with api.Context(w, h, 1, nb, front_split=1) as ctx:   # (the test library: the runs below switch between the round-1 kernels)
         for pipelined in (0, 1, 0):
             ctx.set_option(api.OPT_PIPELINE, pipelined)
             for (src, n, low, high, split, sat) in [(frames, 4, 10, 40, 1, 0), (noise, 1, 30, 90, 0, 1), (frames, 2, 0, 255, 1, 1),
@@ -715,3 +712,15 @@ def test_download_begin_end(oracle):
                     assert ctx.hysteresis_totals()[1] == 2, "the one-launch runs were not continued from the host"
     finally:
         lib.hc_host_free(C.c_void_p(hout))
+
+
+def test_product_library_refuses_the_round1_front_forms():
+    """HC_OPT_FRONT_SPLIT 1 / 0 in mode R name kernels the product library no longer contains: refused, not ignored (mode O
+    keeps its 4-px kernel)."""
+    with api.Context(64, 64, 1, 1) as ctx:
+        for v in (0, 1):
+            with pytest.raises(api.HipCannyError):
+                ctx.set_option(api.OPT_FRONT_SPLIT, v)
+        ctx.set_option(api.OPT_FRONT_SPLIT, 2)
+    with api.Context(64, 64, 1, 1, mode=api.MODE_O) as ctx:
+        ctx.set_option(api.OPT_FRONT_SPLIT, 0)

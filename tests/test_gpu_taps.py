@@ -36,8 +36,7 @@ def _want(oracle, img, low, high, saturate=False):
 def test_front_taps_mono(oracle, name, img, form, split):
     h, w = img.shape
     blur, thr, edges = _want(oracle, img, 10, 40)
-    with api.Context(w, h, 1, 1) as ctx:
-        ctx.set_option(api.OPT_FRONT_SPLIT, split)
+    with api.Context(w, h, 1, 1, front_split=split) as ctx:
         ctx.set_option(api.OPT_DEBUG_TAPS, 1)
         got = ctx.process(img)[0]
         _diff(ctx.debug_tap(api.TAP_BLUR)[0], blur, f"{name} {form}: blur of the front kernels")
@@ -51,10 +50,9 @@ def test_front_taps_thresholds_and_batch(oracle, form, split, pipeline):
     """Other thresholds, the saturating NMS variant, a batch, pipelined mode (provisional map on)."""
     frames = np.stack([synth.natural(520, 300, 31), synth.noise(520, 300, 32), synth.steps(520, 300, 250, "diagonal")])
     for low, high, sat in ((10, 40, 0), (60, 200, 0), (0, 255, 0), (25, 25, 1)):
-        with api.Context(520, 300, 1, 3) as ctx:
+        with api.Context(520, 300, 1, 3, front_split=split) as ctx:
             ctx.set_thresholds(low, high)
             ctx.set_option(api.OPT_NMS_SATURATE, sat)
-            ctx.set_option(api.OPT_FRONT_SPLIT, split)
             ctx.set_option(api.OPT_PIPELINE, pipeline)
             ctx.set_option(api.OPT_DEBUG_TAPS, 1)
             got = ctx.process(frames)
@@ -74,16 +72,14 @@ def test_front_taps_bgr_and_per_channel(oracle, form, split):
     img[40:90, 100:300] = (200, 30, 90)
     mono = oracle.gray_bgr(img)
     blur, thr, edges = _want(oracle, mono, 10, 40)
-    with api.Context(501, 130, 3, 1) as ctx:  # BGR -> grey fused into the front kernel's load
-        ctx.set_option(api.OPT_FRONT_SPLIT, split)
+    with api.Context(501, 130, 3, 1, front_split=split) as ctx:  # BGR -> grey fused into the front kernel's load
         ctx.set_option(api.OPT_DEBUG_TAPS, 1)
         got = ctx.process(img)[0]
         _diff(ctx.debug_tap(api.TAP_BLUR)[0], blur, f"bgr {form}: blur")
         _diff(ctx.debug_tap(api.TAP_THRESH)[0], thr, f"bgr {form}: bit planes")
         _diff(got, edges, f"bgr {form}: edges")
-    with api.Context(501, 130, 3, 1) as ctx:  # one map per channel: output frame 3 f + ch
+    with api.Context(501, 130, 3, 1, front_split=split) as ctx:  # one map per channel: output frame 3 f + ch
         ctx.set_option(api.OPT_PER_CHANNEL, 1)
-        ctx.set_option(api.OPT_FRONT_SPLIT, split)
         ctx.set_option(api.OPT_DEBUG_TAPS, 1)
         n = ctx.upload(img)
         ctx.run(api.CannyStage.HYSTER, n)

@@ -11,7 +11,10 @@ cd /tmp && export TMPDIR=/tmp
 # the stats pass profiles the command itself (python3 bench.py <args>); the counter passes use a short run of it
 # (6 timed + 2 warm-up steps = 8 launches: two of each content of the default rotation of four)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python3 $R/bench.py "$@" > "$OUT/bench_under_rocprof_stats.json" 2> "$OUT/stats.log"
-cp "$OUT"/stats/*/*kernel_stats.csv "$OUT/kernel_stats.csv" 2>/dev/null
+# (the bench's host-fed leg starts tools/bin/stream_bench as a child process, which rocprofv3 traces into files of its own:
+#  the bench process itself is the one with the biggest trace)
+big=$(ls -S "$OUT"/stats/*/*kernel_trace.csv 2>/dev/null | head -1)
+cp "${big%kernel_trace.csv}kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
 python3 "$R/tools/trace_summary.py" "$OUT/stats" > "$OUT/one_step_trace.txt" 2>&1
 for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo "$pass" | cut -d' ' -f1)

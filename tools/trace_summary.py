@@ -8,7 +8,8 @@ import glob
 import sys
 
 path = sys.argv[1]
-f = sorted(glob.glob(path + "/**/*kernel_trace.csv", recursive=True))[-1]
+import os
+f = max(glob.glob(path + "/**/*kernel_trace.csv", recursive=True), key=os.path.getsize)   # the bench process, not the child processes of its host-fed leg
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 dur = collections.Counter()
 for r in rows:
