@@ -492,11 +492,6 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   // the non-strict NMS of the 6 output rows against the rows above / below in registers and the neighbours' columns by
   // DPP -> one byte of each plane and 8 bytes of provisional map per lane and row, stored once (no zero-stores, no queue,
   // no LDS beyond the 10 row reads).  ~260 instructions per row whatever the content.  The arithmetic is the batch's.
-#ifdef F8_NO_DENSE  // experiments: the kernel without the dense path
-  constexpr bool dense = false;
-#else
-  bool dense = p.dense_enter < 0;  // this window takes the dense path (HC_OPT_FRONT_DENSE = 1: every window, tests)
-#endif
   auto dense_window = [&](int bw0, u32 sbase) {
     // pixels outside the image have zero gradients (cannyEdgeD.cu:142-149, 222-229): half-word masks of the lane's aligned pairs
     const u32 pm[4] = { __builtin_amdgcn_perm(0u, cmask[0], 0x01010000u), __builtin_amdgcn_perm(0u, cmask[0], 0x03030202u),
@@ -616,8 +611,9 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   for (int j = 0; j < G; ++j) xn[j] = load_raw(r0 + j);
   const int nwin = (rend + 2 - (r0 - 2) + F8_SUB - 1) / F8_SUB;
   int bslot0 = 0;  // blur-ring slot of the window's first blur row (blur row r0 - 2 sits in slot 0)
-#pragma nounroll
-  for (int w = 0; w < nwin; ++w) {
+  // one window; DENSE: its phase 2 is the dense path.  (A lambda instantiated twice, for two separate loops below.)
+  auto window = [&](auto dense_c, int w) {
+    constexpr bool DENSE = decltype(dense_c)::value;
     const int bw0 = r0 - 2 + w * F8_SUB;  // the window's blur rows are bw0 .. bw0+5 (its last input row is bw0 + 7)
     qn = 0;
 #pragma unroll
@@ -686,7 +682,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     }
     int sb = bslot0 - 4;  // blur-ring slot of blur row bw0 - 4
     if (sb < 0) sb += F8_RING;
-    if (__builtin_expect(dense, false)) {  // (laid out after the kernel's hot blocks)
+    if constexpr (DENSE) {
       dense_window(bw0, (u32)sb);
     } else {
       wq = 0;
@@ -699,15 +695,34 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
       step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
       while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
     }
-    // the next window: dense when this one queued (or, on the dense path, counted) many half-lanes; with hysteresis
-#ifndef F8_NO_DENSE
-    dense = wq > (dense ? p.dense_leave : p.dense_enter);
-#endif
     wave_lds_sync();  // the next window's phase 1 overwrites the oldest ring rows
     if (IN == 2) __syncthreads();  // the three channels of this run stay within a window of each other (see above)
     bslot0 = bslot0 + F8_SUB >= F8_RING ? bslot0 + F8_SUB - F8_RING : bslot0 + F8_SUB;
+  };
+  // Two loops, not one loop with a branch in it: the dense path needs more SGPRs than the kernel has (its compare masks),
+  // and with the branch inside the window loop the spills it caused were paid by every window of every frame (+2 % on
+  // frames that never take the path).  A window that queued more than p.dense_enter half-lanes hands over to the dense
+  // loop, a dense window that counted fewer than p.dense_leave hands back.
+  int w = 0;
+#ifdef F8_NO_DENSE
+  for (; w < nwin; ++w) window(std::false_type{}, w);
+#else
+  bool dense = p.dense_enter < 0;  // HC_OPT_FRONT_DENSE = 1: every window (tests)
+  while (w < nwin) {
+#pragma nounroll
+    for (; w < nwin && !dense; ++w) {
+      window(std::false_type{}, w);
+      dense = wq > p.dense_enter;
+    }
+#pragma nounroll
+    for (; w < nwin && dense; ++w) {
+      window(std::true_type{}, w);
+      dense = wq > p.dense_leave;
+    }
   }
+#endif
 }
+
 
 // =====================================================================================================================
 // k_front8o -- Mode O (cv::Canny(src, low, high, 3, L2gradient) semantics, OpenCV 4.x modules/imgproc/src/canny.cpp) on
