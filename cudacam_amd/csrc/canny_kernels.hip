@@ -1104,6 +1104,7 @@ hipError_t launch_hyst_loop(const HystParams &p, int rounds, u32 *bar, hipStream
   const size_t tiles = (size_t)p.nframes * p.nrtiles;
   if (p.npanels != 1 || p.RD != 64 || tiles == 0 || tiles > (size_t)HYST_LOOP_MAX_TILES || rounds < 1 || !bar || !p.wl_reason || p.wl_stride < tiles) return hipErrorInvalidValue;
   if (p.tile_rows == 16 && p.waves == 8) hipLaunchKernelGGL((k_hyst_loop<16, 8>), dim3((unsigned)tiles), dim3(512), 0, s, p, rounds, bar);
+
   else if (p.tile_rows == 32 && p.waves == 2) hipLaunchKernelGGL((k_hyst_loop<32, 2>), dim3((unsigned)tiles), dim3(128), 0, s, p, rounds, bar);
   else return hipErrorInvalidValue;
   return hipGetLastError();

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -18,6 +19,7 @@ namespace {
 // the two copy streams all HC_OPT_COPY_STREAMS contexts of a device share (created on first use, kept for the process)
 constexpr int MAX_DEVICES = 64;
 hipStream_t g_h2d[MAX_DEVICES] = { nullptr }, g_d2h[MAX_DEVICES] = { nullptr };
+std::mutex g_copy_streams_mutex;  // contexts of different host threads may ask for them at the same time
 thread_local std::string g_err;
 int fail(int code, const std::string &msg)
 {
@@ -995,6 +997,7 @@ int hc_set_option(hc_ctx *c, int option, int value)
     if (c->dl_host) return fail(HC_E_STATE, "HC_OPT_COPY_STREAMS: a download is in flight");
     HIPCK(hipSetDevice(c->device));
     if (value && c->device < MAX_DEVICES) {
+      std::lock_guard<std::mutex> lock(g_copy_streams_mutex);
       if (!g_h2d[c->device]) HIPCK(hipStreamCreateWithFlags(&g_h2d[c->device], hipStreamNonBlocking));
       if (!g_d2h[c->device]) HIPCK(hipStreamCreateWithFlags(&g_d2h[c->device], hipStreamNonBlocking));
       if (!c->ev_up) HIPCK(hipEventCreateWithFlags(&c->ev_up, hipEventDisableTiming));
