@@ -1,5 +1,6 @@
 """Randomised parity sweep (tests/fuzz_parity.py): sizes 1..2200 x 1..400, six kinds of content, both modes, every
-option (saturating NMS, the three front-path forms, run lengths, L2 gradient, BGR / per-channel / 3-channel Mode O input),
+option (saturating NMS, the three front-path forms, k_front8's half-strip form and dense path forced on / off / automatic,
+run lengths, L2 gradient, BGR / per-channel / 3-channel Mode O input),
 batches of 1..3 frames, the fast path's own blur and bit planes in a third of the Mode R cases -- product vs oracle, bit for bit.  The longer runs (thousands of cases) are done by hand with the tool."""
 import os
 import subprocess
