@@ -215,6 +215,27 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     work_launches, continued = ctx.hysteresis_info()
     in_staged, out_staged, front_form = ctx.last_run_info()
 
+    # Untimed extra leg (rank 0, N = 1, rotation on): rounds 1-2 measured ONE natural batch processed every step; the same
+    # here over a few steps, so that the line carries the figure that compares with theirs.  Never part of `value`.
+    same_batch = None
+    if rot > 1 and world == 1 and not brief:
+        nsame = max(8, min(24, steps))
+        for k in range(3):   # warm: the adaptive estimates settle on this content
+            ctx.run_device(d_ins[0].data_ptr(), W * C, W * C * H, d_outs[k % len(d_outs)].data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
+        ctx.sync()
+        ctx.profile_get(reset=True)
+        ts0 = time.perf_counter()
+        for k in range(nsame):
+            ctx.run_device(d_ins[0].data_ptr(), W * C, W * C * H, d_outs[k % len(d_outs)].data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
+        ctx.sync()
+        ts1 = time.perf_counter()
+        ssums, sruns = ctx.profile_get(reset=True)
+        sfront = ssums[1] / max(sruns, 1)
+        same_batch = {"content": kinds[0], "steps": nsame, "value": round(B * nsame / (ts1 - ts0), 1), "unit": "frames/s", "ms_per_step": round((ts1 - ts0) / nsame * 1e3, 4),
+                      "kernel_ms": round(sfront, 4),
+                      "roofline_frac": round(float(W * H * C + W * H * (3 if a.per_channel else 1)) * B / (sfront * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if sfront > 0 else None,
+                      "note": "the same natural batch every step (the workload of rounds 1-2; bench.py --rotate 1 times it as the headline)"}
+
     elapsed = shard.reduce_max_seconds(t1 - t0, dist if world > 1 else None, dev if backend == "nccl" else None)   # (gloo reduces host tensors)
 
     if rank == 0:
@@ -261,6 +282,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
             "hysteresis": {"launches_with_work": work_launches, "continued": h_continued, "runs": h_runs,
                            "launches_with_work_mean": round(h_work / max(h_runs, 1), 2), "launches_queued_mean": round(h_queued / max(h_runs, 1), 2)},
             "by_content": _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch),
+            "same_batch_every_step": same_batch,
             # the caller's buffers were used in place (no hidden staging copies) and the front path that actually ran
             "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {4: "k_front8 (half-strip form)", 3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form)},
         }

@@ -15,7 +15,8 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats"
 #  the bench process itself is the one with the biggest trace)
 big=$(ls -S "$OUT"/stats/*/*kernel_trace.csv 2>/dev/null | head -1)
 cp "${big%kernel_trace.csv}kernel_stats.csv" "$OUT/kernel_stats.csv" 2>/dev/null
-python3 "$R/tools/trace_summary.py" "$OUT/stats" > "$OUT/one_step_trace.txt" 2>&1
+case " $* " in *" --rotate 1 "*) ts=1 ;; *) ts=4 ;; esac   # the default rotation: one turn of its four contents
+TRACE_STEPS=$ts python3 "$R/tools/trace_summary.py" "$OUT/stats" "$OUT/bench_under_rocprof_stats.json" > "$OUT/one_step_trace.txt" 2>&1
 for pass in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum TCC_MISS_sum"; do
   n=$(echo "$pass" | cut -d' ' -f1)
   timeout 300 rocprofv3 --kernel-trace --pmc $pass --output-format csv -d "$OUT/pmc_$n" -- python3 $R/bench.py --steps ${PMC_STEPS:-6} --warmup ${PMC_WARMUP:-2} --no-cpu-baseline --no-host-fed "$@" > /dev/null 2> "$OUT/pmc_$n.log"

@@ -1,14 +1,18 @@
 #!/usr/bin/env python3
-"""Per-dispatch timeline of one steady-state bench step from a rocprofv3 kernel-trace CSV: start (us, relative), duration,
-kernel, grid size.  The step shown is the third-last launch of the front kernel that dominates the trace (the timed
-configuration, not the short host-fed leg that follows it) and everything up to the next such launch."""
+"""Per-dispatch timeline of steady-state bench steps from a rocprofv3 kernel-trace CSV: start (us, relative), duration,
+kernel, grid size.  First the duration of EVERY launch of the front kernel that dominates the trace, in launch order (the
+warm-up, the timed steps, then the bench's untimed legs: same-batch, host-fed, output check); then the timeline of
+TRACE_STEPS consecutive steps (default 1; 4 = one turn of the default content rotation) beginning a third of the way into
+those launches, i.e. inside the timed region of the default command and of the profile commands.  With the bench's JSON
+line as second argument: the mean duration of the timed launches beside the figure bench.py measured with HIP events."""
 import collections
 import csv
 import glob
+import os
 import sys
 
 path = sys.argv[1]
-import os
+nsteps = int(os.environ.get("TRACE_STEPS", "1"))
 f = max(glob.glob(path + "/**/*kernel_trace.csv", recursive=True), key=os.path.getsize)   # the bench process, not the child processes of its host-fed leg
 rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 dur = collections.Counter()
@@ -20,8 +24,20 @@ if not dur:
     sys.exit("no front kernel in the trace")
 main = dur.most_common(1)[0][0]
 idx = [i for i, r in enumerate(rows) if r["Kernel_Name"] == main]
-a = idx[-3] if len(idx) >= 3 else idx[0]
-b = idx[idx.index(a) + 1] + 1 if idx.index(a) + 1 < len(idx) else len(rows)
+print("front kernel launches in order, us: " + " ".join(f'{(int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3:.0f}' for i in idx))
+if len(sys.argv) > 2:   # the bench's JSON line: mean over its timed launches (kernel_stats.csv averages every launch of the process, untimed legs included)
+    import json
+    try:
+        j = json.loads(open(sys.argv[2]).read().strip().splitlines()[-1])
+        w, s = int(j["warmup"]), int(j["steps"])
+        timed = [(int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e6 for i in idx[w:w + s]]
+        print(f'timed launches {w} .. {w + s - 1}: mean {sum(timed) / len(timed):.4f} ms (bench.py reports kernel_ms {j["roofline"]["kernel_ms"]} from HIP events)')
+    except Exception as e:   # a summary tool: say so and carry on
+        print("no bench line to compare with:", e)
+k = len(idx) // 3
+a = idx[k]
+b = idx[k + nsteps] if k + nsteps < len(idx) else len(rows)
+print(f"timeline of launches {k} .. {k + nsteps - 1} of {len(idx)}:")
 t0 = int(rows[a]["Start_Timestamp"])
 for r in rows[a:b]:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
