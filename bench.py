@@ -282,6 +282,9 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
             "hysteresis": {"launches_with_work": work_launches, "continued": h_continued, "runs": h_runs,
                            "launches_with_work_mean": round(h_work / max(h_runs, 1), 2), "launches_queued_mean": round(h_queued / max(h_runs, 1), 2)},
             "by_content": _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch),
+            "by_content_note": ("step_ms = device-side interval between the completion of the previous run and of this one (front kernel + this "
+                                "run's hysteresis tail - the previous run's); kernel_ms = this content's front kernel, which runs BESIDE THE "
+                                "PREVIOUS content's hysteresis (noise: 3.9 ms after a natural batch, 5.0 ms after another noise batch)") if rot > 1 else None,
             "same_batch_every_step": same_batch,
             # the caller's buffers were used in place (no hidden staging copies) and the front path that actually ran
             "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {4: "k_front8 (half-strip form)", 3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form)},

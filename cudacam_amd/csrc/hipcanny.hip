@@ -84,6 +84,9 @@ struct hc_ctx {
   // fused path
   Slot slot[NSLOT];
   int nslot_use = 2;  // slots the pipelined runs rotate through (4 for small batches)
+  int hyst_force_lists = -1;  // HC_HYST_LISTS = 1 / 0: worklists from launch 1 on always / never (experiments)
+  int hyst_mixed_from = 2;  // first launch of a mixed-schedule run that works from lists (HC_HYST_MIXED_FROM: experiments)
+  int pipe_slots = 0;  // experiments (HC_PIPE_SLOTS = 2 .. 4): that many slots whatever the batch size
   int cur = 0;
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
@@ -311,7 +314,7 @@ int copy_frames_d2d(hc_ctx *c, hipStream_t st, void *dst, size_t dpitch, size_t 
 }
 
 // slots the pipelined runs of n_out output frames rotate through: by pixels (16 8K x 3 frames are a big batch)
-int pipeline_slots(const hc_ctx *c, int n_out) { return (long long)n_out * c->H * c->W < 500ll * 1000 * 1000 ? NSLOT : 2; }
+int pipeline_slots(const hc_ctx *c, int n_out) { return c->pipe_slots ? c->pipe_slots : (long long)n_out * c->H * c->W < 500ll * 1000 * 1000 ? NSLOT : 2; }
 
 // Completes a queued fused run: waits for it, and if its queued hysteresis launches did not reach
 // the fixpoint (flag of the last one still set -- adversarial inputs only), keeps iterating, then
@@ -460,6 +463,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // (BGR frames blended into grey: 25 launches, 205 -> 222 k frames/s; the 16 launches of 1080p grey frames fit inside
   // the front kernel's time, and there the lists cost 2 %).
   if (c->hyst_late_grid) hp.lists = c->hyst_late_grid > 0;
+  else if (c->hyst_force_lists >= 0) hp.lists = c->hyst_force_lists;
   else if (hp.npanels > 1) hp.lists = !(c->wl_prev_tiles == hp.wl_stride && (size_t)c->wl_prev[1] * 5 > hp.wl_stride * 3);
   else hp.lists = c->last_work_launches >= 20 || (c->hyst_lists_last && c->last_work_launches >= 14);
   c->hyst_lists_last = hp.lists != 0;
@@ -470,7 +474,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // few long edges through the frame (launch 2 still starts every tile, and writes the first list): 1080p grey 394 -> 405 k
   // frames/s, 256 frames per run 307 -> 317 k; with the lists from launch 1 on: 400 k, from launch 4: 404 k.  (The list
   // streams above keep their lists from launch 1: BGR 259 against 252 k, 8K x 3 8.76 against 8.64 k; 4K would gain 2 %.)
-  int mixed_from = (!hp.lists && !c->hyst_late_grid && small_tiles) ? 2 : 0;
+  int mixed_from = (!hp.lists && !c->hyst_late_grid && small_tiles) ? c->hyst_mixed_from : 0;
   // A small run (a few frames): all K rounds in one launch, device-wide barriers between them (k_hyst_loop) -- K host
   // calls and K trips through the command processor fewer per run; a run it cannot finish (its workgroups not resident
   // together, or more rounds needed than queued) is continued by finish_slot like any other.
@@ -712,7 +716,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       else {
         const long units = waves_per_chunk;
         long nch = std::max<long>(1, (H + 60) / 120);
-        if (units * nch < 3072) nch = std::min<long>((3072 + units - 1) / units, std::max(1, H / 8));
+        if (units * nch < 3072) nch = std::min<long>((3072 + units - 1) / units, std::max(1, H / 8));  // (spread over 2048 / 1536 / 1024 waves instead: no better, profiles/r03/experiments.md)
         rows = (int)((H + nch - 1) / nch);
       }
       const int windows = std::max(1, (rows + 4 + 5) / 6);
@@ -875,6 +879,9 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   c->hyst_diag = getenv("HC_HYST_DIAG") != nullptr;
   if (const char *e = getenv("HC_HYST_LATE_GRID")) c->hyst_late_grid = std::max(-1, atoi(e));  // tests: tiny grids exercise the hand-on of worklist entries
   if (const char *e = getenv("HC_HYST_LOOP")) c->hyst_loop = atoi(e) != 0;
+  if (const char *e = getenv("HC_HYST_LISTS")) c->hyst_force_lists = atoi(e) != 0;
+  if (const char *e = getenv("HC_HYST_MIXED_FROM")) c->hyst_mixed_from = std::min(8, std::max(1, atoi(e)));
+  if (const char *e = getenv("HC_PIPE_SLOTS")) c->pipe_slots = std::min(NSLOT, std::max(0, atoi(e))) == 1 ? 2 : std::min(NSLOT, std::max(0, atoi(e)));
   if (const char *e = getenv("HC_HYST_LIST_FLOOR")) c->hyst_list_floor = std::max(1, atoi(e));
   if (const char *e = getenv("HC_HYST_GEOM")) {
     int tr = 0, wv = 0;
