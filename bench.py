@@ -160,7 +160,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     d_in = d_ins[0]
     n_out = 3 * B if a.per_channel else B
     # output batches used in turn, as a pipelined consumer would (run i's maps are read while run i+1 computes): as many
-    # as the context keeps runs in flight (hc_pipeline_depth: 2, or 4 for small batches); with a single one the library
+    # as the context keeps runs in flight (hc_pipeline_depth: 3 for big batches -- two slots, a third while the hysteresis chain bounds the step -- 4 for small ones); with a single one the library
     # falls back to the non-provisional expand to keep run i+1's map intact
     # (--front split / fused4 in mode R: the round-1 kernels live in the test library, cudacam_amd/libhipcanny_legacy.so)
     ctx = api.Context(W, H, C, B, api.MODE_R if a.mode == "R" else api.MODE_O, device=local,
@@ -214,6 +214,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     sums, nruns = ctx.profile_get(reset=True)
     work_launches, continued = ctx.hysteresis_info()
     in_staged, out_staged, front_form = ctx.last_run_info()
+    slots_used = ctx.pipeline_slots_in_use()   # 2, or 3 once the context saw the hysteresis chain outlast the next front kernel
 
     # Untimed extra leg (rank 0, N = 1, rotation on): rounds 1-2 measured ONE natural batch processed every step; the same
     # here over a few steps, so that the line carries the figure that compares with theirs.  Never part of `value`.
@@ -265,6 +266,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
                      f"synthetic, {rot} different batches in rotation ({', '.join(kinds)}); {nat_per} distinct frames per natural / blend batch, 8 per noise batch, tiled to the batch"),
             "content_rotation": rot,
             "output_buffers": len(d_outs),
+            "pipeline_slots": slots_used,
             "config": {"workload": (f"configs[1]: 1920x1080 grayscale, full 5-stage HIP pipeline, batch {B} frames/step/GPU" if (W, H, a.mode) == (1920, 1080, "R")
                                     else f"{W}x{H} " + ("grayscale" if C == 1 else "BGR, per-channel Canny" if a.per_channel else "BGR -> grey") + f", mode {a.mode}, batch {B} frames/step/GPU"),
                        "width": W, "height": H, "batch": B, "low": LOW, "high": HIGH, "sharding": f"frames x{world}",

@@ -41,10 +41,10 @@ constexpr int WL_COUNT_WORDS = 128;
 static_assert(WL_COUNT_WORDS >= MAX_HYST_LAUNCHES + 1 + 2, "a count per launch, one beyond the last, and the two words of k_hyst_loop's barrier");
 
 // Everything one in-flight fused run owns.  Two slots let run i+1's front kernel overlap run i's hysteresis (pipelined
-// mode); the plain mode only uses slot 0.  (Three were measured on big batches: run i+1 then no longer waits for the
-// hysteresis of run i-1 -- no difference at 1080p in either mode, at 4K, with BGR input or at 8K x 3: where the step is
-// longer than the front kernel, it is the hysteresis stream that is full, and a third slot only lets it fall further
-// behind.)  SMALL batches use four slots, each with a hysteresis stream of its own: there a step is the latency of the
+// mode); the plain mode only uses slot 0.  Big batches rotate through two -- or three, while the hysteresis chain of a run
+// is seen to outlast the front kernel of the next (finish_slot; 8K x 3: 6.9 -> 7.8 k frames/s, 8K grey 25.3 -> 27.5 k;
+// where the front kernel bounds the step a third slot costs 1 %, a fourth 4 %: profiles/r03/experiments.md).
+// SMALL batches use four slots, each with a hysteresis stream of its own: there a step is the latency of the
 // hysteresis' chain of dependent launches (8 frames: 0.33 ms for a 0.04 ms front kernel), and chains of different runs
 // share the device without noticing each other.
 constexpr int NSLOT = 4;
@@ -67,6 +67,7 @@ struct Slot {
   int hyst_level = 0;            // tile height level of this run's hysteresis (hc_ctx::hyst_obs index)
   int mixed_from = 0;            // > 0: launches below it ran a workgroup per tile, launch `mixed_from` wrote the first list, the rest took lists
   uintptr_t out0 = 0, out1 = 0;  // output range of this (pipelined, still pending) run: a later run into the same memory waits for it
+  unsigned long long seq = 0;    // number of the pipelined run that uses the slot (hc_ctx::run_seq)
 };
 }  // namespace
 
@@ -87,6 +88,10 @@ struct hc_ctx {
   int hyst_force_lists = -1;  // HC_HYST_LISTS = 1 / 0: worklists from launch 1 on always / never (experiments)
   int hyst_mixed_from = 2;  // first launch of a mixed-schedule run that works from lists (HC_HYST_MIXED_FROM: experiments)
   int pipe_slots = 0;  // experiments (HC_PIPE_SLOTS = 2 .. 4): that many slots whatever the batch size
+  int big_slots = 2;   // slots of big pipelined batches: 2, or 3 while the hysteresis chain bounds the step (finish_slot)
+  int chain_bound_runs = 0, chain_light_runs = 0, chain_light_needed = 16;
+  int chain_told = 0;  // diagnostics (HC_OPT_PIPELINE_SLOTS 20 / 21): +1 / -1 = every chain counts as ending after / before the next front kernel
+  unsigned long long run_seq = 0;
   int cur = 0;
   bool pipeline = false;
   int per_channel = 0;  // 3-channel input: one edge map per channel (3 output frames per input frame)
@@ -200,8 +205,8 @@ int alloc_slot_parts(hc_ctx *c, Slot &s)
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     HIPCK(hipStreamCreateWithPriority(&s.s_hyst, hipStreamNonBlocking, greatest));
   }
-  HIPCK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));
-  HIPCK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
+  HIPCK(hipEventCreate(&s.ev_front));  // (with timestamps: finish_slot compares the end of a run's hysteresis with the end of the next front kernel)
+  HIPCK(hipEventCreate(&s.ev_done));
   return HC_OK;
 }
 
@@ -314,7 +319,38 @@ int copy_frames_d2d(hc_ctx *c, hipStream_t st, void *dst, size_t dpitch, size_t 
 }
 
 // slots the pipelined runs of n_out output frames rotate through: by pixels (16 8K x 3 frames are a big batch)
-int pipeline_slots(const hc_ctx *c, int n_out) { return c->pipe_slots ? c->pipe_slots : (long long)n_out * c->H * c->W < 500ll * 1000 * 1000 ? NSLOT : 2; }
+int pipeline_slots(const hc_ctx *c, int n_out) { return c->pipe_slots ? c->pipe_slots : (long long)n_out * c->H * c->W < 500ll * 1000 * 1000 ? NSLOT : c->big_slots; }
+
+// Two or three slots for big pipelined batches?  With two, the front kernel of run i+2 waits for the hysteresis of run i,
+// which runs beside the front kernel of run i+1: while that chain of launches is the shorter of the two nothing waits,
+// and a third slot would only let a second chain compete for the same wave slots (-1 % at 1080p).  Where the chain
+// outlasts the next front kernel (8K: 30 dependent launches over 68 row tiles and 4 column panels) the front kernels
+// sit idle for the difference, and a third slot lets run i+2 start on time.  Decided from the slots' own events:
+// three runs in a row whose chain ended after the next run's front kernel -> three slots; back to two after 16 runs in a
+// row (doubling each time, up to 1024) whose chain ended before the next front kernel did.
+void watch_chain(hc_ctx *c, const Slot &s)
+{
+  if (c->pipe_slots || !s.seq || s.stream == c->stream || c->nslot_use >= NSLOT) return;
+  for (const Slot &o : c->slot) {
+    if (o.seq != s.seq + 1 || !o.ev_front) continue;
+    float ms = 0.0f;
+    const hipError_t e = hipEventElapsedTime(&ms, o.ev_front, s.ev_done);  // the next front kernel's end -> this run's end
+    if (e != hipSuccess) (void)hipGetLastError();                           // (not ready: that kernel still runs -- the chain was the shorter)
+    const bool outlasts = c->chain_told ? c->chain_told > 0 : (e == hipSuccess && ms > 0.0f);
+    if (c->nslot_use == 2) {
+      c->chain_bound_runs = outlasts ? c->chain_bound_runs + 1 : 0;
+      if (c->chain_bound_runs >= 3) { c->big_slots = 3; c->chain_bound_runs = c->chain_light_runs = 0; }
+    } else {
+      c->chain_light_runs = outlasts ? 0 : c->chain_light_runs + 1;
+      if (c->chain_light_runs >= c->chain_light_needed) {
+        c->big_slots = 2;
+        c->chain_light_needed = std::min(1024, 2 * c->chain_light_needed);
+        c->chain_bound_runs = c->chain_light_runs = 0;
+      }
+    }
+    return;
+  }
+}
 
 // Completes a queued fused run: waits for it, and if its queued hysteresis launches did not reach
 // the fixpoint (flag of the last one still set -- adversarial inputs only), keeps iterating, then
@@ -326,6 +362,7 @@ int finish_slot(hc_ctx *c, Slot &s)
   s.out0 = s.out1 = 0;  // (this function only returns when the run is complete)
   hipStream_t st = s.stream;
   HIPCK(hipEventSynchronize(s.ev_done));
+  watch_chain(c, s);
   const int K = s.k_launches;
   int work = 0;
   for (int k = 0; k < K; ++k) work += s.h_flags[k] != 0;
@@ -536,7 +573,9 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
   if (piped) {
     if (int rc = alloc_slot(c, s)) return rc;
     if (int rc = finish_slot(c, s)) return rc;  // the run that used this slot NSLOT steps ago
+    s.seq = ++c->run_seq;
   } else if (int rc = finish_all(c)) return rc;
+  else s.seq = 0;
   // streams: the front kernels always run on the context stream, in order with the caller's own work on it (whatever
   // it did to the input before this call, whatever it does to it afterwards); pipelined mode puts the rest on s_hyst.
   // (A separate front stream tied to the context stream by events cost a 50 us bubble per run: every cross-stream wait
@@ -1013,6 +1052,10 @@ int hc_set_option(hc_ctx *c, int option, int value)
       if (!c->ev_down) HIPCK(hipEventCreateWithFlags(&c->ev_down, hipEventDisableTiming));
     }
     c->copy_streams = value != 0 && c->device < MAX_DEVICES;
+  } else if (option == HC_OPT_PIPELINE_SLOTS) {
+    if (value == -1 || value == 20 || value == 21) { c->pipe_slots = 0; c->chain_told = value == 20 ? 1 : value == 21 ? -1 : 0; }
+    else if (value == 2 || value == 3) c->pipe_slots = value;
+    else return fail(HC_E_ARG, "HC_OPT_PIPELINE_SLOTS: -1 (automatic), 2, 3, or 20 / 21 (diagnostics)");
   } else if (option == HC_OPT_FRONT_DENSE) {
     if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_DENSE: -1 (automatic), 0 (never) or 1 (every window)");
     c->dense_mode = value;
@@ -1338,7 +1381,14 @@ int hc_pipeline_depth(hc_ctx *c, int nframes)
 {
   if (!c || nframes <= 0) return fail(HC_E_ARG, "hc_pipeline_depth: null context or nframes <= 0");
   if (!c->pipeline) return 1;
-  return pipeline_slots(c, c->per_channel ? 3 * nframes : nframes);
+  const int n = pipeline_slots(c, c->per_channel ? 3 * nframes : nframes);
+  return (n < NSLOT && !c->pipe_slots) ? 3 : n;  // big batches: two slots, three while the hysteresis chain bounds the step (watch_chain)
+}
+
+int hc_pipeline_slots_in_use(hc_ctx *c)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  return c->pipeline ? c->nslot_use : 1;
 }
 
 int hc_last_run_info(hc_ctx *c, int *input_staged, int *output_staged, int *front_form)

@@ -157,11 +157,15 @@ int hc_hysteresis_totals(hc_ctx *ctx, unsigned long long totals[4], int reset);
  * (tight rows of a width that is not a multiple of 8) are staged (*input_staged = 1) so that the 8-px kernels can run. */
 int hc_last_run_info(hc_ctx *ctx, int *input_staged, int *output_staged, int *front_form);
 
-/* Pipelined mode: how many runs of `nframes` frames the context keeps in flight (2, or 4 for small batches -- fewer
- * than 0.5 G pixels per run; 1 when HC_OPT_PIPELINE is off): the number of output buffers a caller should rotate
- * through so that no run has to wait for an older one that still writes the same memory.  No reference counterpart
+/* Pipelined mode: how many runs of `nframes` frames the context may keep in flight (4 for small batches -- fewer
+ * than 0.5 G pixels per run; big batches: 3 -- the context uses two slots, and a third while it sees the hysteresis of
+ * a run outlast the front kernel of the next (frames of several thousand columns); 1 when HC_OPT_PIPELINE is off):
+ * the number of output buffers a caller should rotate through so that no run has to wait for an older one that still
+ * writes the same memory.  No reference counterpart
  * (the reference processes one frame per synchronous call, src/cvp/cannyEdgeH.cu:49-120). */
 int hc_pipeline_depth(hc_ctx *ctx, int nframes);
+/* ... and how many slots the ring of the most recent pipelined run had (2 / 3 / 4; 1 when HC_OPT_PIPELINE is off). */
+int hc_pipeline_slots_in_use(hc_ctx *ctx);
 
 /* Diagnostics of the last run's queued hysteresis launches: 3 words per launch
  * (sweeps summed over tiles, max sweeps of a tile, tiles that did work). */
@@ -225,9 +229,15 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * device, one for device -> host -- tied to the context stream by events, instead of on the context stream itself.
  * Copies that share a stream with kernels do not overlap across contexts on this runtime (three contexts, 32 MiB
  * batches: 28 GB/s each way; with the two copy streams 40, with 64 MiB batches 47 of the 48 GB/s the link carries both
- * ways at once -- tools/pcie_raw2.hip). */
+ * ways at once -- tools/pcie_raw2.hip).
+ *
+ * HC_OPT_PIPELINE_SLOTS (default -1 = automatic): the ring of big pipelined batches.  Automatic: two slots, and a third
+ * while the context sees the hysteresis of a run end after the front kernel of the next one (hc_pipeline_depth).
+ * 2 or 3 fixes the ring.  Diagnostics / tests: 20 / 21 = the automatic rule, but told that every chain ends after /
+ * before the next front kernel, which walks it through its transitions (2 -> 3 after three runs, 3 -> 2 after sixteen)
+ * whatever the content.  Same results with every value. */
 enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6, HC_OPT_FRONT_HALF = 7,
-       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9 };
+       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9, HC_OPT_PIPELINE_SLOTS = 10 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* The fast path's own intermediates of the last HC_STAGE_HYSTER run (HC_OPT_DEBUG_TAPS must have been set before it),

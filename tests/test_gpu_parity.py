@@ -436,7 +436,7 @@ def test_small_batches_keep_four_runs_in_flight(oracle, nbuf):
     with api.Context(w, h, 1, 4000) as ctx:
         assert ctx.pipeline_depth(nb) == 1
         ctx.set_option(api.OPT_PIPELINE, 1)
-        assert ctx.pipeline_depth(nb) == 4 and ctx.pipeline_depth(1400) == 4 and ctx.pipeline_depth(4000) == 2   # 0.5 G pixels = 3906 of these frames
+        assert ctx.pipeline_depth(nb) == 4 and ctx.pipeline_depth(1400) == 4 and ctx.pipeline_depth(4000) == 3   # 0.5 G pixels = 3906 of these frames
         for rep in range(2):
             last = {}
             for r in range(len(runs)):
@@ -451,6 +451,57 @@ def test_small_batches_keep_four_runs_in_flight(oracle, nbuf):
                 got = ctx.process(big)
                 for f in (0, 1700, 3999):
                     _diff(got[f], oracle.canny_r(big[f], 10, 40), f"big batch between the small ones, frame {f}")
+
+
+def test_big_batches_take_a_third_slot_when_the_hysteresis_chain_bounds_the_step(oracle):
+    """Big pipelined batches rotate through two slots, and through three once the context has seen the hysteresis chain of
+    a run end after the front kernel of the next one (hipcanny.hip, watch_chain).  Whether that happens depends on the
+    content and on the machine, so the rule is also walked through its transitions by hand (HC_OPT_PIPELINE_SLOTS 20 / 21:
+    every chain counts as the longer / the shorter): 2 -> 3 after three runs, 3 -> 2 after sixteen, the ring resized with
+    runs in flight -- and the maps are the oracle's whichever ring is in use, with three output buffers and with two (a
+    run into memory that an older run still writes waits for it), and with the ring fixed at 3 or 2."""
+    import torch
+    w, h, nb = 640, 200, 4000   # 0.51 G pixels: a big batch
+    uniq = np.stack([synth.serpentine(w, h, amp=20 + (f % 5), seed_amp=120) if f % 2 else synth.natural(w, h, 700 + f) for f in range(8)])
+    want = oracle.canny_r_batch(uniq, 10, 40, threads=4)
+    d_in = torch.from_numpy(np.tile(uniq, (nb // 8, 1, 1))).cuda()
+    d_out = [torch.zeros((nb, h, w), dtype=torch.uint8, device="cuda") for _ in range(3)]
+
+    def runs(ctx, n, nbuf, tag):
+        for r in range(n):
+            ctx.run_device(d_in.data_ptr(), w, w * h, d_out[r % nbuf].data_ptr(), w, w * h, nb)
+        ctx.sync()
+        for k, o in enumerate(d_out[:nbuf]):
+            got = o[:: nb // 16].cpu().numpy()   # frames 0, 250, 500, ...: every distinct frame twice
+            for j in range(got.shape[0]):
+                _diff(got[j], want[(j * (nb // 16)) % 8], f"{tag}, buffer {k}, frame {j * (nb // 16)}")
+            o.zero_()
+
+    with api.Context(w, h, 1, nb) as ctx:
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        assert ctx.pipeline_depth(nb) == 3
+        runs(ctx, 8, 3, "automatic")
+        assert ctx.pipeline_slots_in_use() in (2, 3)
+        ctx.set_option(api.OPT_PIPELINE_SLOTS, 20)
+        runs(ctx, 8, 3, "told that every chain outlasts the next front kernel")
+        assert ctx.pipeline_slots_in_use() == 3
+        runs(ctx, 5, 2, "three slots, two output buffers")
+        ctx.set_option(api.OPT_PIPELINE_SLOTS, 21)
+        runs(ctx, 26, 3, "told that every chain ends first")
+        assert ctx.pipeline_slots_in_use() == 2
+        ctx.set_option(api.OPT_PIPELINE_SLOTS, 20)
+        runs(ctx, 8, 3, "and up again")
+        assert ctx.pipeline_slots_in_use() == 3
+        ctx.set_option(api.OPT_PIPELINE_SLOTS, 21)
+        runs(ctx, 26, 3, "the way down takes twice as many runs the second time")
+        assert ctx.pipeline_slots_in_use() == 3
+        for forced in (2, 3):
+            ctx.set_option(api.OPT_PIPELINE_SLOTS, forced)
+            assert ctx.pipeline_depth(nb) == forced
+            runs(ctx, 7, 3, f"ring fixed at {forced}")
+            assert ctx.pipeline_slots_in_use() == forced
+        with pytest.raises(api.HipCannyError):
+            ctx.set_option(api.OPT_PIPELINE_SLOTS, 5)
 
 
 def test_python_mirror_of_reference_operator(oracle):
