@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n0) : "s"(mh0) : "scc");
     asm("s_bcnt1_i32_b64 %0, %1" : "=s"(n1) : "s"(mh1) : "scc");
     qcount += (int)(n0 + n1);
-    wq += (int)(n0 + n1);
+    // (rows 0, 1, H-2, H-1 are not counted: the zero padding makes them candidates across the whole width of every frame)
+    wq += (c >= 2 && c < H - 2) ? (int)(n0 + n1) : 0;
   };
 
   // One dense NMS pass: up to 64 queued half-lanes, an entry per lane.  sbase: blur-ring slot of blur row bw0 - 4.
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
         const u32 g0 = max(max(SC[1], SC[2]), max(SC[3], SC[4])), g1 = max(max(SC[5], SC[6]), max(SC[7], SC[8]));
         // the same measure as the queue path's: half-lanes with a pixel above the low threshold
         const u64 mh0 = __ballot(g0 >= a_lo0) & (valid ? lanes0 : 0ull), mh1 = __ballot(g1 >= a_lo0) & (valid ? lanes1 : 0ull);
-        cnt += __popcll(mh0) + __popcll(mh1);
+        cnt += (c >= 2 && c < H - 2) ? __popcll(mh0) + __popcll(mh1) : 0;
         if (valid) {
           const bool wraps = __ballot(max(g0, g1) >= wrap_limit) != 0;
           u32 bitsS = 0, bitsC = 0;

@@ -85,6 +85,7 @@ struct hc_ctx {
   // fused path
   Slot slot[NSLOT];
   int nslot_use = 2;  // slots the pipelined runs rotate through (4 for small batches)
+  int dense_enter = 512, dense_leave = 384;  // HC_DENSE_ENTER / HC_DENSE_LEAVE (experiments)
   int hyst_force_lists = -1;  // HC_HYST_LISTS = 1 / 0: worklists from launch 1 on always / never (experiments)
   int hyst_mixed_from = 2;  // first launch of a mixed-schedule run that works from lists (HC_HYST_MIXED_FROM: experiments)
   int pipe_slots = 0;  // experiments (HC_PIPE_SLOTS = 2 .. 4): that many slots whatever the batch size
@@ -727,8 +728,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       // scheme costs 27 + 41 + 3.6 e instructions per row for e queued half-lanes, the dense path ~260: break-even near
       // 320 per window -- but the zero padding makes the first two rows of every frame candidates across the whole
       // width, and with 320 the window after them went dense on every natural frame: +1.2 % on the benchmark's frames.)
-      fp.dense_enter = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : 512;
-      fp.dense_leave = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : 384;
+      fp.dense_enter = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : c->dense_enter;
+      fp.dense_leave = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : c->dense_leave;
       long waves_per_chunk = (long)n_out * fp.nstrips;
       if (c->mode == HC_MODE_R && c->dump_region && c->half_mode != 0) {
         // HALF form (narrow frames): the (frame, 240-column half-strip) units of a run of rows are dealt to half-waves in
@@ -918,6 +919,8 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   c->hyst_diag = getenv("HC_HYST_DIAG") != nullptr;
   if (const char *e = getenv("HC_HYST_LATE_GRID")) c->hyst_late_grid = std::max(-1, atoi(e));  // tests: tiny grids exercise the hand-on of worklist entries
   if (const char *e = getenv("HC_HYST_LOOP")) c->hyst_loop = atoi(e) != 0;
+  if (const char *e = getenv("HC_DENSE_ENTER")) c->dense_enter = std::max(0, atoi(e));
+  if (const char *e = getenv("HC_DENSE_LEAVE")) c->dense_leave = std::max(0, atoi(e));
   if (const char *e = getenv("HC_HYST_LISTS")) c->hyst_force_lists = atoi(e) != 0;
   if (const char *e = getenv("HC_HYST_MIXED_FROM")) c->hyst_mixed_from = std::min(8, std::max(1, atoi(e)));
   if (const char *e = getenv("HC_PIPE_SLOTS")) c->pipe_slots = std::min(NSLOT, std::max(0, atoi(e))) == 1 ? 2 : std::min(NSLOT, std::max(0, atoi(e)));
