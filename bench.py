@@ -214,6 +214,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     sums, nruns = ctx.profile_get(reset=True)
     work_launches, continued = ctx.hysteresis_info()
     in_staged, out_staged, front_form = ctx.last_run_info()
+    front_waves = ctx.front_waves_per_workgroup() if a.mode == "R" else None   # k_front8: 4, or 1 while the hysteresis stream has the slack (HC_OPT_FRONT_WPB)
     slots_used = ctx.pipeline_slots_in_use()   # 2, or 3 once the context saw the hysteresis chain outlast the next front kernel
 
     # Untimed extra leg (rank 0, N = 1, rotation on): rounds 1-2 measured ONE natural batch processed every step; the same
@@ -289,7 +290,8 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
                                 "PREVIOUS content's hysteresis (noise: 3.9 ms after a natural batch, 5.0 ms after another noise batch)") if rot > 1 else None,
             "same_batch_every_step": same_batch,
             # the caller's buffers were used in place (no hidden staging copies) and the front path that actually ran
-            "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {4: "k_front8 (half-strip form)", 3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form)},
+            "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {4: "k_front8 (half-strip form)", 3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form),
+                        "front_waves_per_workgroup": front_waves},
         }
         # HBM bytes per launch of the front kernels from the committed PMC passes (separate rocprofv3 runs of this
         # command, tools/collect_profiles.sh); only quoted when that profile was taken on this very configuration

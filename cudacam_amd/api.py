@@ -49,6 +49,7 @@ OPT_FRONT_HALF = 7
 OPT_FRONT_DENSE = 8
 OPT_COPY_STREAMS = 9
 OPT_PIPELINE_SLOTS = 10
+OPT_FRONT_WPB = 11
 TAP_BLUR, TAP_THRESH = 1, 2
 
 # every symbol include/hipcanny.h declares
@@ -56,7 +57,7 @@ ABI_SYMBOLS = [
     "hc_create", "hc_destroy", "hc_set_thresholds", "hc_get_thresholds", "hc_upload", "hc_run", "hc_run_device",
     "hc_hysteresis_device", "hc_download", "hc_sync", "hc_set_stream", "hc_enable_profiling", "hc_stage_time_ms", "hc_profile_get",
     "hc_device_ptrs", "hc_last_hysteresis_info", "hc_hysteresis_stats", "hc_set_tuning", "hc_set_option", "hc_selftest", "hc_last_error", "hc_version",
-    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals", "hc_last_run_info", "hc_pipeline_depth", "hc_pipeline_slots_in_use",
+    "hc_host_alloc", "hc_host_free", "hc_profile_get_front", "hc_debug_tap", "hc_use_own_stream", "hc_profile_get_intervals", "hc_last_run_info", "hc_pipeline_depth", "hc_pipeline_slots_in_use", "hc_front_waves_per_workgroup",
     "hc_profile_get_front_each", "hc_hysteresis_totals", "hc_download_begin", "hc_download_end",
 ]
 
@@ -130,6 +131,7 @@ def load_library(legacy=False):
     L.hc_last_run_info.argtypes = [vp, C.POINTER(i), C.POINTER(i), C.POINTER(i)]
     L.hc_pipeline_depth.argtypes = [vp, i]
     L.hc_pipeline_slots_in_use.argtypes = [vp]
+    L.hc_front_waves_per_workgroup.argtypes = [vp]
     L.hc_profile_get_intervals.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(i)]
     L.hc_profile_get_front_each.argtypes = [vp, C.POINTER(C.c_float), i, C.POINTER(i)]
     L.hc_hysteresis_totals.argtypes = [vp, C.POINTER(C.c_ulonglong), i]
@@ -288,6 +290,13 @@ class Context:
     def hysteresis_device(self, d_thr, in_pitch, in_fs, d_out, out_pitch, out_fs, nframes):
         _ck(self.lib.hc_hysteresis_device(self.handle, C.c_void_p(d_thr), in_pitch, in_fs, C.c_void_p(d_out), out_pitch,
                                           out_fs, int(nframes)))
+
+    def front_waves_per_workgroup(self):
+        """Waves per workgroup of the most recent k_front8 launch (hc_front_waves_per_workgroup): 4, 1 or 3."""
+        r = self.lib.hc_front_waves_per_workgroup(self.handle)
+        if r < 0:
+            _ck(r)
+        return r
 
     def pipeline_slots_in_use(self):
         """Slots of the ring the most recent pipelined run used (hc_pipeline_slots_in_use)."""

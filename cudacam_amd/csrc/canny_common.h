@@ -56,6 +56,7 @@ struct FrontParams {
   // reason words: one memset kernel and one host call fewer per run); null: nothing
   u32 *zero_words; u32 zero_count;
   int half;        // k_front8: HALF form (two 240-column half-strips per wave, narrow frames); nstrips is unused then
+  int one_wave;    // k_front8, mono / BGR with a provisional map: one-wave workgroups instead of four-wave ones
   int nhalf;       // HALF form: half-strips per frame = ceil(W / 240); total_items = ceil(in_frames * nhalf / 2) * nchunks (* 3 per-channel)
   // k_front8: a window that follows one with more than dense_enter half-lanes above the low threshold takes the dense path
   // (wave-wide NMS in registers), and the windows after it while they count more than dense_leave (0x7FFFFFFF: never)

@@ -96,7 +96,10 @@ static __device__ __forceinline__ u32 f8_chain(const unsigned char *ring, u32 sl
 // so the two halves of a wave may belong to different strips and to different (adjacent) frames.  Rows, and with them all
 // control flow, stay wave-uniform; what depends on the strip or the frame becomes a per-lane offset.  The DPP wave shifts
 // need no fence between lanes 31 and 32: both are halo lanes, whose far neighbour is never consumed.
-template <int IN, bool PROV, bool HALF>
+// ONE: one-wave workgroups (mono / BGR).  A retiring wave's slot is then refilled at once -- a four-wave workgroup needs a free
+// slot on each of the CU's four SIMDs at the same moment -- which gains the front kernel 2-3 % beside the hysteresis and
+// costs the hysteresis 40 % more stream time: the host picks it while that stream has the slack (hipcanny.hip, watch_chain).
+template <int IN, bool PROV, bool HALF, bool ONE = false>
 __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   // strip, run), a wave each, kept within one window of each other by a barrier per window -- so the 24 interleaved bytes
   // per lane and row are fetched from HBM once and served to the other two waves from the CU's L1 / the XCD's L2.
   // (Without the barrier the three drifted apart and the input was fetched about twice: 5.5 GB per 16 8K frames.)
-  constexpr int WPB = IN == 2 ? 3 : F8_WPB;
+  constexpr int WPB = IN == 2 ? 3 : ONE ? 1 : F8_WPB;
   // the flag words of this run's hysteresis (a few hundred to 140 k dwords), zeroed by the first workgroups on their way in
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < p.zero_count; i += gridDim.x * blockDim.x) p.zero_words[i] = 0u;
   int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPB + wib);
@@ -1036,6 +1039,15 @@ static hipError_t launch_front8_t(const FrontParams &p, hipStream_t s)
 {
   constexpr int WPB = IN == 2 ? 3 : F8_WPB;
   if (IN == 2 && p.total_items % 3 != 0) return hipErrorInvalidValue;
+  if constexpr (IN != 2) {
+    if (p.one_wave) {  // (only beside a hysteresis, i.e. with the provisional map)
+      if (!p.prov_out) return hipErrorInvalidValue;
+      const dim3 grid1((unsigned)p.total_items), block1(64);
+      if (p.half) hipLaunchKernelGGL((k_front8<IN, true, true, true>), grid1, block1, (size_t)F8_WAVE_BYTES, s, p);
+      else hipLaunchKernelGGL((k_front8<IN, true, false, true>), grid1, block1, (size_t)F8_WAVE_BYTES, s, p);
+      return hipGetLastError();
+    }
+  }
   const dim3 grid((unsigned)((p.total_items + WPB - 1) / WPB)), block(64 * WPB);
   const size_t lds = (size_t)WPB * F8_WAVE_BYTES;
   if (p.half) {

@@ -89,8 +89,18 @@ struct hc_ctx {
   int hyst_force_lists = -1;  // HC_HYST_LISTS = 1 / 0: worklists from launch 1 on always / never (experiments)
   int hyst_mixed_from = 2;  // first launch of a mixed-schedule run that works from lists (HC_HYST_MIXED_FROM: experiments)
   int pipe_slots = 0;  // experiments (HC_PIPE_SLOTS = 2 .. 4): that many slots whatever the batch size
+  // timestamps of the last pipelined runs, by run number & 7: front kernel finished / hysteresis finished (watch_chain)
+  hipEvent_t ring_f[8] = {}, ring_d[8] = {};
+  unsigned long long ring_seq[8] = {};
+  int front_wpb_mode = -1;   // HC_OPT_FRONT_WPB: -1 = by the slack of the hysteresis stream, 1 / 4 = fixed
+  bool front_one = false;    // the automatic choice: one-wave workgroups for k_front8 (mono / BGR, pipelined big batches)
+  float slack_ema = 0.0f;    // share of a front kernel's time by which the previous run's hysteresis chain ended before it (smoothed)
+  int last_front_waves = 4;  // waves per workgroup of the most recent k_front8 launch
   int big_slots = 2;   // slots of big pipelined batches: 2, or 3 while the hysteresis chain bounds the step (finish_slot)
   int chain_bound_runs = 0, chain_light_runs = 0, chain_light_needed = 16;
+  float period_ms[4] = { 0, 0, 0, 0 }, period_two = 0.0f;  // the last four steps (front kernel end to front kernel end); their mean before the trial of a third slot
+  int trial_runs = -1;                                      // >= 0: runs since the third slot was taken on trial
+  int retry_wait = 0, retry_backoff = 64;                   // runs until the next trial after one that did not pay (doubling)
   int chain_told = 0;  // diagnostics (HC_OPT_PIPELINE_SLOTS 20 / 21): +1 / -1 = every chain counts as ending after / before the next front kernel
   unsigned long long run_seq = 0;
   int cur = 0;
@@ -322,26 +332,60 @@ int copy_frames_d2d(hc_ctx *c, hipStream_t st, void *dst, size_t dpitch, size_t 
 // slots the pipelined runs of n_out output frames rotate through: by pixels (16 8K x 3 frames are a big batch)
 int pipeline_slots(const hc_ctx *c, int n_out) { return c->pipe_slots ? c->pipe_slots : (long long)n_out * c->H * c->W < 500ll * 1000 * 1000 ? NSLOT : c->big_slots; }
 
-// Two or three slots for big pipelined batches?  With two, the front kernel of run i+2 waits for the hysteresis of run i,
-// which runs beside the front kernel of run i+1: while that chain of launches is the shorter of the two nothing waits,
-// and a third slot would only let a second chain compete for the same wave slots (-1 % at 1080p).  Where the chain
-// outlasts the next front kernel (8K: 30 dependent launches over 68 row tiles and 4 column panels) the front kernels
-// sit idle for the difference, and a third slot lets run i+2 start on time.  Decided from the slots' own events:
-// three runs in a row whose chain ended after the next run's front kernel -> three slots; back to two after 16 runs in a
-// row (doubling each time, up to 1024) whose chain ended before the next front kernel did.
+// What the hysteresis chain of a run did to the front kernel it ran beside, from timestamps of the runs themselves
+// (ring_f / ring_d: recorded behind every pipelined run's front kernel and behind its last hysteresis launch).  Called
+// when run i is complete: the chain of run i-1 ran beside the front kernel of run i, and all three events involved --
+// end of front i-1, end of chain i-1, end of front i -- are complete.
+//  * Two or three slots for big batches?  With two, the front kernel of run i+2 waits for the hysteresis of run i: while
+//    that chain is the shorter of the two nothing waits, and a third slot only lets a second chain compete for the same
+//    wave slots (-1 % at 1080p).  Where the chain outlasts the front kernel (8K: 30 dependent launches over 68 row tiles
+//    and 4 column panels) the front kernels sit idle for the difference, and a third slot lets the next run start on
+//    time.  Three runs in a row whose chain ended after the front kernel beside it -> a third slot ON TRIAL: kept if
+//    the mean step of runs 7-10 with it is 3 % shorter than the last four steps without (8K x 3: -11 %, 8K grey -8 %,
+//    256 frames of 1080p -5 %), otherwise given back, next trial after 64 runs, doubling; from three back to two after
+//    16 runs in a row (doubling, up to 1024) whose chain ended first.
+//  * One-wave or four-wave workgroups for k_front8?  One-wave workgroups take every slot a retiring wave leaves at once:
+//    the front kernel gains 2-3 %, the hysteresis stream needs 40 % longer -- good while that stream has the time
+//    (1080p grey: it ends 40 % of a front kernel early; +1.5 % frames/s), bad where it has none (BGR -> grey: -5 %).
+//    By the smoothed share of the front kernel's time that the chain left unused: above 25 % -> one wave (1080p grey 41 %,
+//    640 x 480 32 %, 4K 27 %; BGR -> grey 5 %), and back to four below 3 % (with one-wave workgroups the same streams
+//    leave 17 %, 7 %, 15 %; BGR -> grey would fall 90 % behind).
 void watch_chain(hc_ctx *c, const Slot &s)
 {
-  if (c->pipe_slots || !s.seq || s.stream == c->stream || c->nslot_use >= NSLOT) return;
-  for (const Slot &o : c->slot) {
-    if (o.seq != s.seq + 1 || !o.ev_front) continue;
-    float ms = 0.0f;
-    const hipError_t e = hipEventElapsedTime(&ms, o.ev_front, s.ev_done);  // the next front kernel's end -> this run's end
-    if (e != hipSuccess) (void)hipGetLastError();                           // (not ready: that kernel still runs -- the chain was the shorter)
-    const bool outlasts = c->chain_told ? c->chain_told > 0 : (e == hipSuccess && ms > 0.0f);
-    if (c->nslot_use == 2) {
+  if (!s.seq || s.stream == c->stream || c->nslot_use >= NSLOT) return;
+  const unsigned long long i = s.seq;
+  const int a = (int)((i - 1) & 7), b = (int)(i & 7);
+  if (c->ring_seq[b] != i || c->ring_seq[a] != i - 1 || i < 2) return;
+  float front_ms = 0.0f, lead_ms = 0.0f;  // front kernel i (end to end); end of chain i-1 -> end of front kernel i
+  if (hipEventElapsedTime(&front_ms, c->ring_f[a], c->ring_f[b]) != hipSuccess || hipEventElapsedTime(&lead_ms, c->ring_d[a], c->ring_f[b]) != hipSuccess) {
+    (void)hipGetLastError();
+    return;
+  }
+  if (front_ms <= 0.0f) return;
+  const bool outlasts = c->chain_told ? c->chain_told > 0 : lead_ms < 0.0f;
+  c->period_ms[i & 3] = front_ms;  // front kernel end to front kernel end: the step
+  const float period4 = 0.25f * (c->period_ms[0] + c->period_ms[1] + c->period_ms[2] + c->period_ms[3]);
+  if (c->retry_wait > 0) --c->retry_wait;
+  if (!c->pipe_slots) {
+    if (c->nslot_use == 2 && c->big_slots == 2) {
       c->chain_bound_runs = outlasts ? c->chain_bound_runs + 1 : 0;
-      if (c->chain_bound_runs >= 3) { c->big_slots = 3; c->chain_bound_runs = c->chain_light_runs = 0; }
-    } else {
+      if (c->chain_bound_runs >= 3 && i >= 5 && (c->retry_wait == 0 || c->chain_told)) {  // try a third slot
+        c->period_two = period4;
+        c->big_slots = 3;
+        c->trial_runs = 0;
+        c->chain_bound_runs = c->chain_light_runs = 0;
+      }
+    } else if (c->nslot_use == 3 && c->trial_runs >= 0) {  // the trial: ten runs, the last four measured
+      if (++c->trial_runs >= 10) {
+        c->trial_runs = -1;
+        const bool better = c->chain_told ? c->chain_told > 0 : period4 < 0.97f * c->period_two;
+        if (!better) {
+          c->big_slots = 2;
+          c->retry_wait = c->retry_backoff;
+          c->retry_backoff = std::min(4096, 2 * c->retry_backoff);
+        }
+      }
+    } else if (c->nslot_use == 3) {
       c->chain_light_runs = outlasts ? 0 : c->chain_light_runs + 1;
       if (c->chain_light_runs >= c->chain_light_needed) {
         c->big_slots = 2;
@@ -349,8 +393,11 @@ void watch_chain(hc_ctx *c, const Slot &s)
         c->chain_bound_runs = c->chain_light_runs = 0;
       }
     }
-    return;
   }
+  const float slack = std::max(-1.0f, std::min(1.0f, lead_ms / front_ms));
+  c->slack_ema = 0.75f * c->slack_ema + 0.25f * slack;
+  if (!c->front_one && c->slack_ema > 0.25f) c->front_one = true;
+  else if (c->front_one && c->slack_ema < 0.03f) c->front_one = false;
 }
 
 // Completes a queued fused run: waits for it, and if its queued hysteresis launches did not reach
@@ -801,6 +848,9 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       } else
 #endif
       {
+        // one-wave workgroups: pipelined big batches with the provisional map, mono / BGR (the per-channel form is three waves, one per channel)
+        fp.one_wave = (s.prov && !c->per_channel && c->nslot_use < NSLOT && (c->front_wpb_mode == 1 || (c->front_wpb_mode < 0 && c->front_one))) ? 1 : 0;
+        c->last_front_waves = c->per_channel ? 3 : fp.one_wave ? 1 : 4;
         HIPCK(launch_front8(fp, sf));
         HIPCK(mark(sf, b_mono | B_GAUSS | B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
       }
@@ -815,6 +865,12 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     }
     if (piped) {
       HIPCK(hipEventRecord(s.ev_front, sf));
+      if (s.seq) {
+        const int k = (int)(s.seq & 7);
+        if (!c->ring_f[k]) { HIPCK(hipEventCreate(&c->ring_f[k])); HIPCK(hipEventCreate(&c->ring_d[k])); }
+        HIPCK(hipEventRecord(c->ring_f[k], sf));
+        c->ring_seq[k] = 0;  // (valid once the chain's end is recorded too)
+      }
       HIPCK(hipStreamWaitEvent(sh, s.ev_front, 0));
     }
     if (int rc = queue_hyst_expand(c, s, sh, dst, dp, dfs, n_out, piped, zeroed_words)) return rc;
@@ -855,6 +911,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     c->ev_count++;
   }
   if (stage == HC_STAGE_HYSTER) HIPCK(hipEventRecord(s.ev_done, sh));
+  if (stage == HC_STAGE_HYSTER && piped && s.seq) {
+    HIPCK(hipEventRecord(c->ring_d[s.seq & 7], sh));
+    c->ring_seq[s.seq & 7] = s.seq;
+  }
   c->last_slot = piped ? c->cur : 0;
   if (piped) c->cur = (c->cur + 1) % c->nslot_use;
   c->last_run_n = n_out;
@@ -964,6 +1024,8 @@ void hc_destroy(hc_ctx *c)
   free_debug_buffers(c);
   for (auto &e : c->evpool) if (e) (void)hipEventDestroy(e);
   for (hipEvent_t e : { c->ev_up, c->ev_ready, c->ev_ready2, c->ev_down }) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ring_f) if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : c->ring_d) if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -1055,6 +1117,9 @@ int hc_set_option(hc_ctx *c, int option, int value)
       if (!c->ev_down) HIPCK(hipEventCreateWithFlags(&c->ev_down, hipEventDisableTiming));
     }
     c->copy_streams = value != 0 && c->device < MAX_DEVICES;
+  } else if (option == HC_OPT_FRONT_WPB) {
+    if (value != -1 && value != 1 && value != 4) return fail(HC_E_ARG, "HC_OPT_FRONT_WPB: -1 (automatic), 1 or 4");
+    c->front_wpb_mode = value;
   } else if (option == HC_OPT_PIPELINE_SLOTS) {
     if (value == -1 || value == 20 || value == 21) { c->pipe_slots = 0; c->chain_told = value == 20 ? 1 : value == 21 ? -1 : 0; }
     else if (value == 2 || value == 3) c->pipe_slots = value;
@@ -1386,6 +1451,12 @@ int hc_pipeline_depth(hc_ctx *c, int nframes)
   if (!c->pipeline) return 1;
   const int n = pipeline_slots(c, c->per_channel ? 3 * nframes : nframes);
   return (n < NSLOT && !c->pipe_slots) ? 3 : n;  // big batches: two slots, three while the hysteresis chain bounds the step (watch_chain)
+}
+
+int hc_front_waves_per_workgroup(hc_ctx *c)
+{
+  if (!c) return fail(HC_E_ARG, "null context");
+  return c->last_front_waves;
 }
 
 int hc_pipeline_slots_in_use(hc_ctx *c)

@@ -166,6 +166,8 @@ int hc_last_run_info(hc_ctx *ctx, int *input_staged, int *output_staged, int *fr
 int hc_pipeline_depth(hc_ctx *ctx, int nframes);
 /* ... and how many slots the ring of the most recent pipelined run had (2 / 3 / 4; 1 when HC_OPT_PIPELINE is off). */
 int hc_pipeline_slots_in_use(hc_ctx *ctx);
+/* Waves per workgroup of the most recent k_front8 launch: 4, 1 (HC_OPT_FRONT_WPB) or 3 (per-channel mode: one per channel). */
+int hc_front_waves_per_workgroup(hc_ctx *ctx);
 
 /* Diagnostics of the last run's queued hysteresis launches: 3 words per launch
  * (sweeps summed over tiles, max sweeps of a tile, tiles that did work). */
@@ -231,13 +233,19 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * batches: 28 GB/s each way; with the two copy streams 40, with 64 MiB batches 47 of the 48 GB/s the link carries both
  * ways at once -- tools/pcie_raw2.hip).
  *
+ * HC_OPT_FRONT_WPB (default -1 = automatic, Mode R, mono / BGR input): waves per workgroup of k_front8 in pipelined big
+ * batches.  One-wave workgroups refill a retiring wave's slot at once and gain the front kernel 2-3 % beside the
+ * hysteresis of the previous run -- which then needs 40 % more stream time.  Automatic: one wave once that hysteresis
+ * ends more than 25 % of a front kernel's time before the front kernel it runs beside, four again below 3 % (smoothed,
+ * from the runs' own events).  1 or 4 fixes it.  Same results either way; hc_front_waves_per_workgroup says what ran.
+ *
  * HC_OPT_PIPELINE_SLOTS (default -1 = automatic): the ring of big pipelined batches.  Automatic: two slots, and a third
  * while the context sees the hysteresis of a run end after the front kernel of the next one (hc_pipeline_depth).
  * 2 or 3 fixes the ring.  Diagnostics / tests: 20 / 21 = the automatic rule, but told that every chain ends after /
- * before the next front kernel, which walks it through its transitions (2 -> 3 after three runs, 3 -> 2 after sixteen)
+ * before the next front kernel, which walks it through its transitions (2 -> 3 on trial after three runs, kept or given back after ten; 3 -> 2 after sixteen)
  * whatever the content.  Same results with every value. */
 enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6, HC_OPT_FRONT_HALF = 7,
-       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9, HC_OPT_PIPELINE_SLOTS = 10 };
+       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9, HC_OPT_PIPELINE_SLOTS = 10, HC_OPT_FRONT_WPB = 11 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* The fast path's own intermediates of the last HC_STAGE_HYSTER run (HC_OPT_DEBUG_TAPS must have been set before it),

@@ -115,6 +115,39 @@ def test_half_form_pipelined_device_buffers(oracle):
                 d_out[r].zero_()
 
 
+@pytest.mark.parametrize("w,channels", [(640, 1), (1000, 1), (1920, 1), (1000, 3)])
+def test_one_wave_workgroups_pipelined(oracle, w, channels):
+    """HC_OPT_FRONT_WPB: k_front8 in one-wave workgroups (pipelined big batches, mono / BGR) gives the maps of the
+    four-wave form -- plain and half-strip form, device-resident, three output buffers in turn; 0.5 G pixels per run make
+    it a big batch (the small ones keep four waves)."""
+    import torch
+    h = 120
+    nb = 500_000_000 // (w * h) + 1
+    uniq = _frames(w, h, 6, 300 + w) if channels == 1 else np.stack([np.stack([synth.natural(w, h, 400 + 3 * f + c) for c in range(3)], axis=2) for f in range(6)])
+    want = np.stack([oracle.canny_r(f, 10, 40) for f in uniq])
+    reps = (nb + 5) // 6
+    d_in = torch.from_numpy(np.tile(uniq, (reps,) + (1,) * (uniq.ndim - 1))[:nb].copy()).cuda()
+    d_out = [torch.zeros((nb, h, w), dtype=torch.uint8, device="cuda") for _ in range(3)]
+    with api.Context(w, h, channels, nb) as ctx:
+        ctx.set_option(api.OPT_PIPELINE, 1)
+        for mode, waves in ((1, 1), (4, 4), (-1, None)):
+            ctx.set_option(api.OPT_FRONT_WPB, mode)
+            for r in range(7):
+                ctx.run_device(d_in.data_ptr(), w * channels, w * channels * h, d_out[r % 3].data_ptr(), w, w * h, nb)
+            ctx.sync()
+            if waves is not None:
+                assert ctx.front_waves_per_workgroup() == waves
+            else:
+                assert ctx.front_waves_per_workgroup() in (1, 4)
+            for o in d_out:
+                got = o[:: max(1, nb // 24)].cpu().numpy()
+                for j in range(got.shape[0]):
+                    _diff(got[j], want[(j * max(1, nb // 24)) % 6], f"HC_OPT_FRONT_WPB {mode}, {w} wide, {channels} channel(s), frame {j * max(1, nb // 24)}")
+                o.zero_()
+        with pytest.raises(api.HipCannyError):
+            ctx.set_option(api.OPT_FRONT_WPB, 2)
+
+
 def test_ragged_tight_rows_are_staged_onto_the_8px_kernel(oracle):
     """Tight rows whose width is not a multiple of 8 used to fall back to the 4-px kernels; they are staged through the
     internal pitched buffer instead (hc_last_run_info says so) and every frame stays on the one-kernel path."""

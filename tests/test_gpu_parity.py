@@ -457,8 +457,8 @@ def test_big_batches_take_a_third_slot_when_the_hysteresis_chain_bounds_the_step
     """Big pipelined batches rotate through two slots, and through three once the context has seen the hysteresis chain of
     a run end after the front kernel of the next one (hipcanny.hip, watch_chain).  Whether that happens depends on the
     content and on the machine, so the rule is also walked through its transitions by hand (HC_OPT_PIPELINE_SLOTS 20 / 21:
-    every chain counts as the longer / the shorter): 2 -> 3 after three runs, 3 -> 2 after sixteen, the ring resized with
-    runs in flight -- and the maps are the oracle's whichever ring is in use, with three output buffers and with two (a
+    every chain counts as the longer / the shorter): 2 -> 3 on trial after three runs, kept or given back after ten,
+    3 -> 2 after sixteen, the ring resized with runs in flight -- and the maps are the oracle's whichever ring is in use, with three output buffers and with two (a
     run into memory that an older run still writes waits for it), and with the ring fixed at 3 or 2."""
     import torch
     w, h, nb = 640, 200, 4000   # 0.51 G pixels: a big batch
@@ -483,18 +483,28 @@ def test_big_batches_take_a_third_slot_when_the_hysteresis_chain_bounds_the_step
         runs(ctx, 8, 3, "automatic")
         assert ctx.pipeline_slots_in_use() in (2, 3)
         ctx.set_option(api.OPT_PIPELINE_SLOTS, 20)
-        runs(ctx, 8, 3, "told that every chain outlasts the next front kernel")
+        runs(ctx, 8, 3, "told that every chain outlasts the next front kernel: a third slot on trial")
+        assert ctx.pipeline_slots_in_use() == 3
+        runs(ctx, 8, 3, "the trial ends (ten runs), the slot is kept")
         assert ctx.pipeline_slots_in_use() == 3
         runs(ctx, 5, 2, "three slots, two output buffers")
         ctx.set_option(api.OPT_PIPELINE_SLOTS, 21)
-        runs(ctx, 26, 3, "told that every chain ends first")
+        runs(ctx, 26, 3, "told that every chain ends first: back to two after sixteen runs")
         assert ctx.pipeline_slots_in_use() == 2
         ctx.set_option(api.OPT_PIPELINE_SLOTS, 20)
-        runs(ctx, 8, 3, "and up again")
+        runs(ctx, 16, 3, "and up again")
         assert ctx.pipeline_slots_in_use() == 3
         ctx.set_option(api.OPT_PIPELINE_SLOTS, 21)
         runs(ctx, 26, 3, "the way down takes twice as many runs the second time")
         assert ctx.pipeline_slots_in_use() == 3
+        runs(ctx, 12, 3, "... and is taken")
+        assert ctx.pipeline_slots_in_use() == 2
+        ctx.set_option(api.OPT_PIPELINE_SLOTS, 20)
+        runs(ctx, 8, 3, "a trial")
+        assert ctx.pipeline_slots_in_use() == 3
+        ctx.set_option(api.OPT_PIPELINE_SLOTS, 21)
+        runs(ctx, 16, 3, "... that does not pay: the third slot is given back when it ends")
+        assert ctx.pipeline_slots_in_use() == 2
         for forced in (2, 3):
             ctx.set_option(api.OPT_PIPELINE_SLOTS, forced)
             assert ctx.pipeline_depth(nb) == forced
