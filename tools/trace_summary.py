@@ -9,6 +9,7 @@ import collections
 import csv
 import glob
 import os
+import re
 import sys
 
 path = sys.argv[1]
@@ -23,7 +24,15 @@ for r in rows:
 if not dur:
     sys.exit("no front kernel in the trace")
 main = dur.most_common(1)[0][0]
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"] == main]
+
+
+def base(name):
+    """k_front8<IN, PROV, HALF, ONE>: the one-wave and four-wave forms (chosen at run time) count as one kernel."""
+    m = re.match(r"(.*k_front8<[^,>]+,[^,>]+,[^,>]+)", name)
+    return m.group(1) if m else name
+
+
+idx = [i for i, r in enumerate(rows) if base(r["Kernel_Name"]) == base(main)]
 print("front kernel launches in order, us: " + " ".join(f'{(int(rows[i]["End_Timestamp"]) - int(rows[i]["Start_Timestamp"])) / 1e3:.0f}' for i in idx))
 if len(sys.argv) > 2:   # the bench's JSON line: mean over its timed launches (kernel_stats.csv averages every launch of the process, untimed legs included)
     import json
