@@ -849,7 +849,10 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
 #endif
       {
         // one-wave workgroups: pipelined big batches with the provisional map, mono / BGR (the per-channel form is three waves, one per channel)
-        fp.one_wave = (s.prov && !c->per_channel && c->nslot_use < NSLOT && (c->front_wpb_mode == 1 || (c->front_wpb_mode < 0 && c->front_one))) ? 1 : 0;
+        // (small batches, whose four chains overlap anyway: from 0.12 G pixels per run -- 64 frames of 1080p +3.5 %, 128 frames
+        //  +4.5 %; 4 to 32 frames -3 to -6 %: tools/exp_small_wpb.sh)
+        const bool auto_one = c->nslot_use < NSLOT ? c->front_one : (long long)n_out * W * H >= 120ll * 1000 * 1000;
+        fp.one_wave = (s.prov && !c->per_channel && (c->front_wpb_mode == 1 || (c->front_wpb_mode < 0 && auto_one))) ? 1 : 0;
         c->last_front_waves = c->per_channel ? 3 : fp.one_wave ? 1 : 4;
         HIPCK(launch_front8(fp, sf));
         HIPCK(mark(sf, b_mono | B_GAUSS | B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));

@@ -237,7 +237,7 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * batches.  One-wave workgroups refill a retiring wave's slot at once and gain the front kernel 2-3 % beside the
  * hysteresis of the previous run -- which then needs 40 % more stream time.  Automatic: one wave once that hysteresis
  * ends more than 25 % of a front kernel's time before the front kernel it runs beside, four again below 3 % (smoothed,
- * from the runs' own events).  1 or 4 fixes it.  Same results either way; hc_front_waves_per_workgroup says what ran.
+ * from the runs' own events); small batches (fewer than 0.5 G pixels per run): one wave from 0.12 G pixels.  1 or 4 fixes it.  Same results either way; hc_front_waves_per_workgroup says what ran.
  *
  * HC_OPT_PIPELINE_SLOTS (default -1 = automatic): the ring of big pipelined batches.  Automatic: two slots, and a third
  * while the context sees the hysteresis of a run end after the front kernel of the next one (hc_pipeline_depth).

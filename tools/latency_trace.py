@@ -21,6 +21,8 @@ d_outs = [torch.zeros_like(d_in) for _ in range(4)]
 torch.cuda.synchronize()
 with api.Context(W, H, 1, nb) as ctx:
     ctx.set_option(api.OPT_PIPELINE, pipeline)
+    if len(sys.argv) > 3:
+        ctx.set_option(api.OPT_FRONT_WPB, int(sys.argv[3]))   # 1 / 4: waves per workgroup of k_front8 (pipelined runs)
     for k in range(30):
         ctx.run_device(d_in.data_ptr(), W, W * H, d_outs[k % 4].data_ptr(), W, W * H, nb)
         if not pipeline:
