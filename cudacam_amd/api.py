@@ -50,6 +50,7 @@ OPT_FRONT_DENSE = 8
 OPT_COPY_STREAMS = 9
 OPT_PIPELINE_SLOTS = 10
 OPT_FRONT_WPB = 11
+OPT_FRONT_MX = 12
 TAP_BLUR, TAP_THRESH = 1, 2
 
 # every symbol include/hipcanny.h declares

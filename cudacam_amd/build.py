@@ -13,7 +13,7 @@ LIB = os.path.join(HERE, "libhipcanny.so")
 # the same sources + the round-1 front kernels of Mode R (HC_OPT_FRONT_SPLIT 1 / 0): independent implementations for the
 # parity tests, not part of the product
 LIB_LEGACY = os.path.join(HERE, "libhipcanny_legacy.so")
-SOURCES = ["canny_kernels.hip", "front8.hip", "hipcanny.hip"]
+SOURCES = ["canny_kernels.hip", "front8.hip", "front_mx.hip", "hipcanny.hip"]
 LEGACY_SOURCES = SOURCES + ["legacy_front.hip"]
 DEPS = LEGACY_SOURCES + ["canny_common.h", "canny_device.h", os.path.join("..", "..", "include", "hipcanny.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

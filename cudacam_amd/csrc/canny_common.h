@@ -117,6 +117,11 @@ hipError_t launch_front8o(const FrontParams &p, hipStream_t s);  // Mode O on th
 int front8_run_rows(int windows);
 int front8_strips(int W);
 int front8_half_strips(int W);
+// front_mx.hip: Mode R, one-channel frames, the blur and Sobel contractions as i8 MFMAs (strips of 216 columns, runs of
+// 16 * blocks rows); big batches
+hipError_t launch_front_mx(const FrontParams &p, hipStream_t s);
+int front_mx_strips(int W);
+int front_mx_run_rows(int blocks);
 hipError_t launch_hyst(const HystParams &p, hipStream_t s);
 // the first `rounds` launches of the workgroup-per-tile form as ONE launch with device-wide barriers between the rounds
 // (small runs: at most HYST_LOOP_MAX_TILES tiles); bar: two zeroed words (arrival counter, abort flag)

@@ -119,6 +119,7 @@ struct hc_ctx {
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
   int half_mode = -1;   // HC_OPT_FRONT_HALF: -1 automatic, 0 never, 1 whenever the buffers allow it
   int dense_mode = -1;  // HC_OPT_FRONT_DENSE: -1 automatic, 0 never, 1 every window
+  int mx_mode = -1;     // HC_OPT_FRONT_MX: -1 automatic (big batches of one-channel frames), 0 never, 1 whenever the run allows it
   uint8_t *d_dump = nullptr;    // k_front8's dump areas (FrontParams::dump / dump_c / dump_p), followed by its page of zeros (FrontParams::zeros)
   size_t dump_region = 0;       // 0: the plain layout (16 KiB + 32 KiB); otherwise four regions of this size (the HALF form's lane offsets reach a frame further)
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
@@ -764,6 +765,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
     if (!f8 && c->mode == HC_MODE_R) return fail(HC_E_ARG, "this library is built without the round-1 front kernels (HC_OPT_FRONT_SPLIT 1 / 0: libhipcanny_legacy.so)");
 #endif
     size_t zeroed_words = 0;
+    bool use_mx = false;
     if (f8) {  // strips of 496 columns, runs of 6 * windows - 4 rows
       // the 8-px kernels zero the run's hysteresis flag words on their way in: every tile shape has at least 16 rows per tile
       zeroed_words = FLAG_WORDS + WL_COUNT_WORDS + 2 * std::min(s.wl_cap, (size_t)n_out * ((size_t)(H + 15) / 16 + 1) * (size_t)((c->RD + 63) / 64));
@@ -810,6 +812,25 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.run_rows = front8_run_rows(windows);
       fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
       fp.total_items = (int)(waves_per_chunk * fp.nchunks);
+      // k_front_mx (blur and Sobel on the matrix pipe): one-channel frames of Mode R whose runs fill the chip -- its blocks
+      // are 16 rows by 216 columns and every run repeats a 16-row warm-up, so small batches stay with k_front8
+      use_mx = c->mode == HC_MODE_R && form == 2 && fp.bgr == 0 && !fp.half && c->mx_mode != 0 && (unsigned long long)H * sp < (1ull << 32)
+               && sp >= round_up((size_t)W, 4) && (!s.prov || W % 8 == 0)
+               && (c->mx_mode == 1 || (!c->chunk && (long long)n_out * W * H >= 120ll * 1000 * 1000));
+      if (use_mx) {
+        fp.nstrips = front_mx_strips(W);
+        const long units = (long)n_out * fp.nstrips;
+        // runs of about 8 blocks (128 rows) that tile the frame evenly; shorter while the chip (3072 resident waves) is not full
+        const int blocks_h = (H + 15) / 16;
+        long nch = std::max<long>(1, (blocks_h + 4) / 8);
+        if (c->chunk) nch = std::max<long>(1, (H + c->chunk - 1) / c->chunk);
+        else if (units * nch < 3072) nch = std::min<long>((3072 + units - 1) / units, blocks_h);
+        const int blocks = (int)((blocks_h + nch - 1) / nch);
+        fp.run_rows = front_mx_run_rows(blocks);
+        fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
+        fp.total_items = (int)(units * fp.nchunks);
+        c->last_front_form = 5;
+      }
     }
     if (c->mode == HC_MODE_O) {
       // cv::Canny: plain thresholds on the L1 magnitude; long chunks (no LDS slab, 4-row warm-up)
@@ -854,7 +875,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
         const bool auto_one = c->nslot_use < NSLOT ? c->front_one : (long long)n_out * W * H >= 120ll * 1000 * 1000;
         fp.one_wave = (s.prov && !c->per_channel && (c->front_wpb_mode == 1 || (c->front_wpb_mode < 0 && auto_one))) ? 1 : 0;
         c->last_front_waves = c->per_channel ? 3 : fp.one_wave ? 1 : 4;
-        HIPCK(launch_front8(fp, sf));
+        if (use_mx) { c->last_front_waves = 4; HIPCK(launch_front_mx(fp, sf)); }
+        else HIPCK(launch_front8(fp, sf));
         HIPCK(mark(sf, b_mono | B_GAUSS | B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
       }
     }
@@ -1130,6 +1152,9 @@ int hc_set_option(hc_ctx *c, int option, int value)
   } else if (option == HC_OPT_FRONT_DENSE) {
     if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_DENSE: -1 (automatic), 0 (never) or 1 (every window)");
     c->dense_mode = value;
+  } else if (option == HC_OPT_FRONT_MX) {
+    if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_MX: -1 (automatic), 0 (never) or 1 (whenever possible)");
+    c->mx_mode = value;
   } else if (option == HC_OPT_FRONT_HALF) {
     if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_HALF: -1 (automatic), 0 (never) or 1 (whenever possible)");
     HIPCK(hipSetDevice(c->device));

@@ -152,7 +152,7 @@ int hc_hysteresis_totals(hc_ctx *ctx, unsigned long long totals[4], int reset);
 /* What the last hc_run / hc_run_device did with the caller's buffers -- no silent cliffs: *input_staged / *output_staged are
  * 1 when the frames went through the context's internal pitched buffers (an extra device-to-device copy each: pointer,
  * pitch or frame stride not a multiple of 4, or 3-channel mode O rows without whole 12-byte groups), and *front_form is
- * the front path that ran (Mode R: the HC_OPT_FRONT_SPLIT value 2 / 1 / 0, or 4 = k_front8 in its half-strip form; Mode O:
+ * the front path that ran (Mode R: the HC_OPT_FRONT_SPLIT value 2 / 1 / 0, 4 = k_front8 in its half-strip form, or 5 = k_front_mx; Mode O:
  * 3 = k_front8o, -1 = k_front_o; -1 also for final stages below HYSTER).  Rows that do not hold whole 8-pixel groups
  * (tight rows of a width that is not a multiple of 8) are staged (*input_staged = 1) so that the 8-px kernels can run. */
 int hc_last_run_info(hc_ctx *ctx, int *input_staged, int *output_staged, int *front_form);
@@ -243,9 +243,14 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * while the context sees the hysteresis of a run end after the front kernel of the next one (hc_pipeline_depth).
  * 2 or 3 fixes the ring.  Diagnostics / tests: 20 / 21 = the automatic rule, but told that every chain ends after /
  * before the next front kernel, which walks it through its transitions (2 -> 3 on trial after three runs, kept or given back after ten; 3 -> 2 after sixteen)
- * whatever the content.  Same results with every value. */
+ * whatever the content.  Same results with every value.
+ *
+ * HC_OPT_FRONT_MX (default -1 = automatic, Mode R, one-channel frames): k_front_mx, the front path whose two integer
+ * contractions -- the 5x5 Gaussian sum and the 3x3 Sobel sums -- run as i8 MFMAs on the matrix pipe (strips of 216
+ * columns, blocks of 16 rows).  Automatic: runs of at least 0.12 G pixels; 0 = never (k_front8 everywhere); 1 = every run
+ * that allows it (one-channel input, rows of whole dwords).  Same results either way; hc_last_run_info reports form 5. */
 enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6, HC_OPT_FRONT_HALF = 7,
-       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9, HC_OPT_PIPELINE_SLOTS = 10, HC_OPT_FRONT_WPB = 11 };
+       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9, HC_OPT_PIPELINE_SLOTS = 10, HC_OPT_FRONT_WPB = 11, HC_OPT_FRONT_MX = 12 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* The fast path's own intermediates of the last HC_STAGE_HYSTER run (HC_OPT_DEBUG_TAPS must have been set before it),

@@ -36,6 +36,8 @@ for i in range(cases):
         opts["sat"] = int(rng.integers(0, 2)); opts["split"] = int(rng.choice([2, 2, 2, 1, 0])); opts["chunk"] = int(rng.choice([0, 2, 8, 9, 24, 50, 122, 400]))   # split: 2 k_front8, 1 k_blur + k_nms, 0 k_front
         # round 3: the forms of k_front8 -- half-strip form and dense path: automatic, never, always
         opts["half"] = int(rng.choice([-1, -1, 0, 1, 1])); opts["dense"] = int(rng.choice([-1, -1, 0, 1]))
+        # round 4: k_front_mx (blur and Sobel as i8 MFMAs) forced on in a third of the cases (it only takes one-channel k_front8 runs)
+        opts["mx"] = int(rng.choice([-1, 0, 1]))
         want = np.stack([O.canny_r(f, low, high, saturate=bool(opts["sat"])) for f in frames])
     else:
         opts["l2"] = int(rng.integers(0, 2)); opts["split"] = int(rng.choice([2, 2, 0])); opts["chunk"] = int(rng.choice([0, 2, 8, 9, 24, 50, 122, 400]))   # split: 2 k_front8o, 0 k_front_o
@@ -60,7 +62,7 @@ for i in range(cases):
         ctx.set_thresholds(low, high)
         if mode == "R":
             ctx.set_option(api.OPT_NMS_SATURATE, opts["sat"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)
-            ctx.set_option(api.OPT_FRONT_HALF, opts["half"]); ctx.set_option(api.OPT_FRONT_DENSE, opts["dense"])
+            ctx.set_option(api.OPT_FRONT_HALF, opts["half"]); ctx.set_option(api.OPT_FRONT_DENSE, opts["dense"]); ctx.set_option(api.OPT_FRONT_MX, opts["mx"])
         else:
             ctx.set_option(api.OPT_L2_GRADIENT, opts["l2"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)
         taps = mode == "R" and rng.random() < 0.3
@@ -93,7 +95,7 @@ for i in range(cases):
             ctx.set_thresholds(low, high)
             if mode == "R":
                 ctx.set_option(api.OPT_NMS_SATURATE, opts["sat"]); ctx.set_option(api.OPT_FRONT_SPLIT, opts["split"]); ctx.set_tuning(opts["chunk"], 0)
-                ctx.set_option(api.OPT_FRONT_HALF, opts["half"]); ctx.set_option(api.OPT_FRONT_DENSE, opts["dense"])
+                ctx.set_option(api.OPT_FRONT_HALF, opts["half"]); ctx.set_option(api.OPT_FRONT_DENSE, opts["dense"]); ctx.set_option(api.OPT_FRONT_MX, opts["mx"])
             else:
                 ctx.set_option(api.OPT_L2_GRADIENT, opts["l2"])
             ctx.set_option(api.OPT_PIPELINE, 1)
