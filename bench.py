@@ -32,7 +32,7 @@ HBM_MEASURED_COPY_GBPS = 6290.0
 
 
 # hc_last_run_info's front form -> (config name, kernel name)
-FORM_NAME = {2: ("front8", "k_front8"), 4: ("front8-half", "k_front8 (half-strip form)"), 1: ("split", "k_blur+k_nms"), 0: ("fused4", "k_front"), 3: ("k_front8o", "k_front8o"), -1: ("k_front_o", "k_front_o")}
+FORM_NAME = {5: ("front-mx", "k_front_mx"), 2: ("front8", "k_front8"), 4: ("front8-half", "k_front8 (half-strip form)"), 1: ("split", "k_blur+k_nms"), 0: ("fused4", "k_front"), 3: ("k_front8o", "k_front8o"), -1: ("k_front_o", "k_front_o")}
 
 
 def parse():
@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-pipeline", action="store_true", help="disable HC_OPT_PIPELINE (default on: run i+1's VALU-bound front kernel overlaps run i's latency-bound hysteresis on a second stream)")
     ap.add_argument("--out-buffers", type=int, default=0, help="pipelined mode: output buffers used in turn (a run into memory that an earlier, still unfinished run writes waits for that run); 0 = as many as the context keeps runs in flight: 2, or 4 for small batches")
     ap.add_argument("--front", default=None, choices=["front8", "split", "fused4"], help="front path (HC_OPT_FRONT_SPLIT): front8 = one kernel, 8 px per lane (default; Mode O: k_front8o); split = k_blur + k_nms; fused4 = the 4-px fused kernel (Mode O: both = k_front_o)")
+    ap.add_argument("--mx", default="auto", choices=["auto", "never", "always"], help="k_front_mx (HC_OPT_FRONT_MX): the front path with blur and Sobel sums on the matrix pipe; auto = the library's rule")
     ap.add_argument("--dense", default="auto", choices=["auto", "never", "always"], help="k_front8's dense path (HC_OPT_FRONT_DENSE): wave-wide NMS for windows full of candidates")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3], help="3: interleaved BGR input (grey conversion fused into the load)")
@@ -173,6 +174,8 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
 
     ctx.set_thresholds(LOW, HIGH)
     ctx.set_tuning(a.chunk, a.hyst_launches)
+    if a.mx != "auto":
+        ctx.set_option(api.OPT_FRONT_MX, {"never": 0, "always": 1}[a.mx])
     if a.dense != "auto":
         ctx.set_option(api.OPT_FRONT_DENSE, {"never": 0, "always": 1}[a.dense])
     # the context keeps its own (non-blocking) stream: the inputs were produced before the synchronize below, and the
@@ -290,7 +293,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
                                 "PREVIOUS content's hysteresis (noise: 3.9 ms after a natural batch, 5.0 ms after another noise batch)") if rot > 1 else None,
             "same_batch_every_step": same_batch,
             # the caller's buffers were used in place (no hidden staging copies) and the front path that actually ran
-            "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {4: "k_front8 (half-strip form)", 3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form),
+            "buffers": {"input_staged": in_staged, "output_staged": out_staged, "front_form": {5: "k_front_mx", 4: "k_front8 (half-strip form)", 3: "k_front8o", 2: "k_front8", 1: "k_blur+k_nms", 0: "k_front", -1: "k_front_o"}.get(front_form),
                         "front_waves_per_workgroup": front_waves},
         }
         # HBM bytes per launch of the front kernels from the committed PMC passes (separate rocprofv3 runs of this

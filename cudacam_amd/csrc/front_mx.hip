@@ -9,7 +9,7 @@
 //   S(r, c)    = sum K[i][j] x[r+i-2][c+j-2]                      (K = the 5x5 integer Gaussian, sum 159)
 //   sumX, sumY = the 3x3 Sobel sums of the blurred bytes          (cannyEdgeD.cu:158-167)
 // v_mfma_i32_32x32x32_i8 computes both exactly: D[m][n] = sum_k A[m][k] B[k][n] with i8 operands and i32 sums.  Per vertical
-// tap i, A is a constant banded Toeplitz matrix (output column m <- input columns m .. m+4 of a 32-column window) and B is
+// tap i, A is a constant banded Toeplitz matrix (an output column <- input columns +0 .. +4 of a 32-column window) and B is
 // the window itself: lane (n, kh) holds 16 CONTIGUOUS row bytes of the row of its index n -- a plain ds_read_b128 from a
 // row-major LDS ring, shifted by one ring row per tap.  Five MFMAs give 28 columns x 32 lanes of exact S, five more the
 // Sobel sums of 28 columns.  Bytes enter as x ^ 0x80 (signed), which biases S by -128 * 159 (folded into the quotient's
@@ -21,46 +21,58 @@
 // lanes-of-N are 16 rows x 2 adjacent column TILES of 28 columns (lane = q + 16 par + 32 kh: row q, tile parity par, K-half
 // / output half kh), so a block is 4 MFMA groups per stage (8 tiles).  ds_read_b128 off 16-byte alignment runs at 1/6 of
 // the aligned rate (profiles/r04/lds_b128.txt), and tiles 28 columns apart are not aligned: both LDS rings therefore store
-// a row as 8 SEGMENTS of 32 bytes -- segment t = the 32-column window of tile t, its last 4 bytes a copy of the next
-// segment's first 4 -- 272 bytes apart (17 x 16: conflict-free).
-//   input ring  20 rows: x = column - (s0 - 4); tile t's window = x in [28 t, 28 t + 32)  -> blur columns y = 28 t + m
+// a row as 16 bytes of padding + 8 SEGMENTS of 32 bytes -- segment t = the 32-column window of tile t, its last 4 bytes a
+// copy of the next segment's first 4 -- 272 bytes apart (17 x 16: rows spread over the banks).
+//   input ring  20 rows: x = column - (s0 - 4); tile t's window = x in [28 t, 28 t + 32)  -> blur columns y = 28 t + o
 //   blur ring   20 rows: y = column - (s0 - 2); tile u's window = y in [28 u, 28 u + 32)  -> outputs at window pos 2 .. 29,
-//               i.e. image columns s0 + 28 u + m: groups of 4 aligned with the image's dwords (plane nibbles, map dwords)
-// Accumulator register 4 g + j of lane (q, par, kh) is output column m = 8 g + 4 kh + j of tile 2 p + par, row q.
+//               i.e. image columns s0 + 28 u + o: groups of 4 aligned with the image's dwords (plane nibbles, map dwords)
+// The rows of the A matrices are permuted so that accumulator register v of lane (q, par, kh) is output column
+// o = 16 kh + v of tile 2 pp + par, row q: a lane's 16 results are 16 ADJACENT columns -- the blur goes back to LDS as one
+// ds_write_b128, four aligned groups of 4 pixels per lane.
 //
-// A block (output rows R0 .. R0+15):
-//   input    16 new rows (requested a block ahead) -> ^ 0x80 -> input ring (two ds_write_b32 per row: the copy)
-//   blur     4 x (5 ds_read_b128, 5 MFMA) -> per pixel one v_mad_i32_i24: P = S * 105518 (+ bias), byte 3 = floor(S / 159) ^ 0x80,
-//            byte 2 = 0 <=> S % 159 == 0 <=> the float chain cannot be decided by integers (see k_front8); byte permutes pack
-//            4 pixels -> blur ring; flagged lanes queue (lane, group, 16 flag bits)
+// A block b of a run (output rows r0 .. rend): R0 = r0 - 4 + 16 b
+//   input    rows R0+4 .. R0+19 (requested a block ahead; the first block also R0 .. R0+3) -> ^ 0x80 -> input ring, one
+//            ds_write_b32 per row: lanes 0..55 hold the window's dwords, lanes 56..63 load the first dword of a segment once
+//            more and store it as the tail of the segment before
+//   blur     rows R0+2 .. R0+17: 4 x (5 ds_read_b128, 5 MFMA) -> per pixel one v_mad_i32_i24: P = S * 105518 (+ bias), byte 3 =
+//            floor(S / 159) ^ 0x80, byte 2 = 0 <=> S % 159 == 0 <=> the float chain cannot be decided by integers (see
+//            k_front8); byte permutes pack 4 pixels -> blur ring; flagged lanes queue (lane, group, 16 flag bits)
 //   fix-up   the literal 25-fmaf chain for the flagged pixels (0.6 %), from the input ring, over their byte of the blur ring
-//   Sobel    4 x (3 ds_read_b128, 5 MFMA) -> sumX, sumY per pixel -> sumX^2 + sumY^2 summed over an aligned group of 4 pixels
-//            (a NECESSARY condition for "one of them passes the low threshold") -> the groups that pass queue their identity
+//   Sobel    rows R0 .. R0+15: 4 x (3 ds_read_b128, 5 MFMA) -> sumX, sumY per pixel -> sumX^2 + sumY^2 summed over an aligned
+//            group of 4 pixels (a NECESSARY condition for "one of them passes the low threshold") -> the groups that pass
+//            queue their identity
 //   NMS      k_front8's batches: 64 queued groups, one per lane, re-derive the 3 x 6 S2 values around their 4 pixels from
 //            the blur ring, decide direction / non-maximum suppression / thresholds exactly, OR their nibble into a 16-row
 //            plane tile in LDS and store their 4 bytes of provisional map
 //   output   the plane tiles are stored once per block; the map rows were stored as zeros before the batches
+// The Sobel stage lags the blur stage by 4 rows, so a run needs no warm-up block: its first block discards 4 of its 16
+// output rows (they belong to the run above), a run of n blocks covers 16 n - 4 rows.
 // Everything a neighbouring pixel needs is re-read from the LDS rings: nothing is carried between blocks but the rings.
 #include "canny_device.h"
 #include <type_traits>
+
+#ifndef MX_ABL
+#define MX_ABL 0  // timing experiments (tools/build_variant.sh, WRONG results): 1 no NMS batches, 2 no fix-up, 4 no stores, 8 no Sobel stage, 16 no blur stage, 32 no input loads
+#endif
 
 namespace hc {
 
 constexpr int MX_STRIP_W = 216;                      // output columns per strip: 7 tiles of 28 + 20 columns of the eighth
 constexpr int MX_ROWS = 16;                          // rows per block
+constexpr int MX_LAG = 4;                            // the Sobel stage's rows trail the blur stage's by 4
 constexpr int MX_RING = 20;                          // rows per LDS ring
-constexpr int MX_PITCH = 272;                        // bytes per ring row: 8 segments of 32 + 16 (row 0's spare bytes are the dump slot)
+constexpr int MX_SEG0 = 16;                          // a ring row: 16 bytes of padding, then 8 segments of 32 bytes
+constexpr int MX_PITCH = 272;
 constexpr int MX_RING_BYTES = MX_RING * MX_PITCH;    // 5440
-constexpr int MX_DUMP = 256;                         // offset of the dump dword in the input ring
 constexpr int MX_NQ = 512;                           // NMS queue entries (u16), circular
-constexpr int MX_AUX = 2048;                         // fix-up queue (256 dwords) | NMS queue (1024 B) + two plane tiles (2 x 16 x 32 B)
+constexpr int MX_AUX = 2048;                         // fix-up queue (256 dwords) | NMS queue (1024 B); two plane tiles (2 x 16 x 32 B)
 constexpr int MX_WAVE_BYTES = 2 * MX_RING_BYTES + MX_AUX;  // 12928: 12 waves per CU
 constexpr u32 MX_PAD = 0x80808080u;                  // four zero pixels, biased
 constexpr u32 MX_MAGIC = 105518u;                    // ceil(2^24 / 159)
 constexpr u32 MX_C0 = (u32)(20352ull * 105518ull + 0x80000000ull);  // (S - 128 * 159) * M + C0 = S * M + 2^31 (mod 2^32)
 
 int front_mx_strips(int W) { return (W + MX_STRIP_W - 1) / MX_STRIP_W; }
-int front_mx_run_rows(int blocks) { return MX_ROWS * blocks; }
+int front_mx_run_rows(int blocks) { return MX_ROWS * blocks - MX_LAG; }
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
@@ -68,8 +80,9 @@ typedef u32 gu32 __attribute__((aligned(4)));
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef u32x2 __attribute__((aligned(4))) gu32x2;
 
-// The MFMA A operands: lane l holds row m = l % 32, k = 16 (l / 32) .. + 15 (four dwords of four i8).  Output column m of a
-// tile takes the window's columns m .. m + 4; rows m >= 28 are zero (28 outputs per 32-column window).
+// The MFMA A operands: lane l holds row m = l % 32, k = 16 (l / 32) .. + 15 (four dwords of four i8).  Row m produces
+// output column o = 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3) of the tile (so that register v of a lane is column 16 kh + v)
+// from the window's columns o .. o + 4; rows with o >= 28 are zero (28 outputs per 32-column window).
 //   0..2  Gaussian kernel rows 0 / 4, 1 / 3, 2      3, 4  Sobel X, blur rows -1 / +1 and blur row 0      5, 6  Sobel Y, row -1 / row +1
 struct alignas(16) MxATable {
   u32 v[7][64][4];
@@ -78,12 +91,13 @@ struct alignas(16) MxATable {
     constexpr int KR[3][5] = { { 2, 4, 5, 4, 2 }, { 4, 9, 12, 9, 4 }, { 5, 12, 15, 12, 5 } };
     for (int l = 0; l < 64; ++l) {
       const int m = l % 32, kh = l / 32;
+      const int o = 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
       for (int dd = 0; dd < 4; ++dd)
         for (int jj = 0; jj < 4; ++jj) {
-          const int t = 16 * kh + 4 * dd + jj - m;  // tap: window column - output index
+          const int t = 16 * kh + 4 * dd + jj - o;  // tap: window column - output column
           for (int a = 0; a < 7; ++a) {
             int c = 0;
-            if (m < 28) {
+            if (o < 28) {
               if (a < 3) c = (t >= 0 && t <= 4) ? KR[a][t] : 0;
               else if (a == 3) c = t == 1 ? -1 : t == 3 ? 1 : 0;                  // - left + right   (cannyEdgeD.cu:158-162)
               else if (a == 4) c = t == 1 ? -2 : t == 3 ? 2 : 0;
@@ -127,50 +141,66 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
 
   const u32 wbase = (u32)wib * (u32)MX_WAVE_BYTES;     // input ring
   const u32 bbase = wbase + (u32)MX_RING_BYTES;        // blur ring
-  const u32 xbase = bbase + (u32)MX_RING_BYTES;        // fix-up queue | NMS queue + plane tiles
+  const u32 xbase = bbase + (u32)MX_RING_BYTES;        // fix-up queue | NMS queue
   const u32 tbase = xbase + 1024u;                     // plane tiles: [STRONG, CANDIDATE][16 rows][32 B]
+  // where a lane stores what nobody reads: the padding of the input ring's rows, a dword of its own per lane
+  const u32 dump = wbase + (u32)(lane >> 2) * (u32)MX_PITCH + 4u * (u32)(lane & 3);
   auto lds32 = [&](u32 off) -> u32 & { return *reinterpret_cast<u32 *>(smem + off); };
   auto lds16 = [&](u32 off) -> unsigned short & { return *reinterpret_cast<unsigned short *>(smem + off); };
-  auto lds128 = [&](u32 off) -> v4i { return *reinterpret_cast<const v4i *>(smem + off); };
+  auto lds128 = [&](u32 off) -> v4i & { return *reinterpret_cast<v4i *>(smem + off); };
 
   v4i A[7];
 #pragma unroll
   for (int a = 0; a < 7; ++a) A[a] = *reinterpret_cast<const v4i *>(MX_A.v[a][lane]);
 
   // ---- input rows ----------------------------------------------------------------------------------------------------
-  // lane d holds dword d of the strip's input row: columns s0 - 4 + 4 d .. + 3 (57 dwords: x = 0 .. 227)
-  const int icol = s0 - 4 + 4 * lane;
+  // lanes 0..56 hold dword d = lane of the strip's input row: window x = 4 d .. + 3, columns s0 - 4 + x (57 dwords: x = 0 ..
+  // 227); lanes 57..63 hold the first dword of segments 1..7 (x = 28, 56, ..) a second time
+  const int xw = lane <= 56 ? 4 * lane : 28 * (lane - 56);
+  const int icol = s0 - 4 + xw;
   u32 cmask = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) cmask |= (lane <= 56 && icol + k >= 0 && icol + k < W) ? (0xFFu << (8 * k)) : 0u;
+  for (int k = 0; k < 4; ++k) cmask |= (icol + k >= 0 && icol + k < W) ? (0xFFu << (8 * k)) : 0u;
   const u32 ld_off = cmask ? (u32)icol : 0u;  // lanes without an image column read the row's first bytes (masked)
-  const int iseg = lane / 7, ipos = lane % 7;
-  // where the dword goes: its segment, and -- the first dword of a segment -- bytes 28..31 of the segment before
-  const u32 wr1 = wbase + (lane <= 55 ? (u32)(32 * iseg + 4 * ipos) : (u32)MX_DUMP);
-  const u32 wr2 = wbase + ((ipos == 0 && iseg >= 1 && lane <= 56) ? (u32)(32 * (iseg - 1) + 28) : (u32)MX_DUMP);
+  // where the dword goes: lanes 0..55 its place in its segment; lane 56 (x = 224) and lanes 57..63 bytes 28..31 of the segment before
+  const u32 wr1 = wbase + (u32)MX_SEG0 + (lane <= 55 ? (u32)(32 * (lane / 7) + 4 * (lane % 7)) : lane == 56 ? (u32)(32 * 7 + 28) : (u32)(32 * (lane - 57) + 28));
   const uint8_t *frame_base = p.in + (size_t)frame * p.in_frame_stride;
   const u32 in_pitch32 = (u32)p.in_pitch;  // launch_front_mx checks H * pitch < 2^32
   auto load_row = [&](int row) -> u32 {  // unconditional: the row clamped into the image, masked when used
+    if (MX_ABL & 32) return (u32)row;
     u32 lo = ld_off;
     asm volatile("" : "+v"(lo));  // keeps the lane offset out of a hoisted 64-bit VGPR pointer
     return *reinterpret_cast<const gu32 *>(frame_base + (u32)min(max(row, 0), H - 1) * in_pitch32 + lo);
   };
 
   // ---- per-lane constants of the epilogues ------------------------------------------------------------------------------
-  const u32 lcB = (u32)(32 * par + 16 * kh);                       // B operand: the tile's segment, the lane's K half
-  const u32 lcW = bbase + (u32)(32 * par + 4 * kh);                // blur write: the tile's segment, the lane's 4-column group
-  const u32 fm3 = kh ? 0u : 0x80808080u;                           // group g = 3: columns 24..27 exist (kh = 0), 28..31 do not
+  const u32 lcS = (u32)(MX_SEG0 + 32 * par + 16 * kh);             // the tile's segment, the lane's half: B operands, blur writes
+  // the first group of a tile is also the tail of the segment before (tile 0: the row's padding); lanes kh = 1 have no such
+  // group and store into their row's padding instead: 8 bytes a row, a dword per lane
+  const u32 lcC = kh ? 4u * (u32)par : (u32)(MX_SEG0 + 32 * par - 4), lcCstep = kh ? 0u : 64u;
+  const u32 fm3 = kh ? 0u : 0x80808080u;                           // dword 3 of the lane: columns 12..15 exist, 28..31 do not
   const u32 m00 = (strip == 0 && par == 0 && kh == 0) ? 0xFFFF0000u : 0xFFFFFFFFu;  // blur columns -2, -1 of the frame: zero padding
   const bool edge_cols = s0 + 224 > W;                             // the strip's input window reaches past the image
   const u32 a_lo0 = p.a_lo[0], a_hi0 = p.a_hi[0], wrap_limit = p.wrap_limit;
   const int magic = (int)MX_MAGIC, c0 = (int)MX_C0;
-  // Sobel tile 7 only has the five groups that lie left of column s0 + 216
-  const u32 thr32 = (par && kh) ? 0xFFFFFFFFu : a_lo0, thr33 = par ? 0xFFFFFFFFu : a_lo0;
+  // Sobel groups that do not exist: dword 3 of the lanes kh = 1 (columns 28..31 of a tile), and in tile 7 everything right
+  // of column s0 + 216 (its lanes kh = 1 only have dword 0)
+  const u32 thr3 = kh ? 0xFFFFFFFFu : a_lo0, thr7 = (par && kh) ? 0xFFFFFFFFu : a_lo0;
 
   const size_t plane_off = (size_t)frame * H * p.RD * 4;
   uint8_t *splane = reinterpret_cast<uint8_t *>(p.sbits) + plane_off;
   uint8_t *cplane = reinterpret_cast<uint8_t *>(p.cbits) + plane_off;
   const u32 plane_pitch = (u32)p.RD * 4u;
+  // A strip's 27 plane bytes of a row start at byte 27 * strip: byte stores are slow (14 of them per block cost 0.4 ms of a
+  // 2.3 ms launch, profiles/r04/mx_ablation.txt).  The plane tiles in LDS are therefore kept in the global dwords'
+  // alignment -- the strip's byte k is tile byte psh + k, psh = (27 * strip) % 4 -- and a row goes out as its 6 whole
+  // dwords (96 a block: lanes 0..63, then 0..31) and its 3 leading / trailing bytes (48 a block: lanes 0..47)
+  const u32 psh = (u32)(27 * strip) & 3u, pd0 = psh ? 1u : 0u, pnh = psh ? 4u - psh : 0u;
+  const u32 pg0 = (u32)(27 * strip) - psh;  // the row's byte offset of tile byte 0
+  const u32 pdA = (u32)lane / 6u, pdAo = 4u * (pd0 + (u32)lane % 6u);                  // dword store 1: row, tile byte
+  const u32 pdB = (64u + (u32)lane) / 6u, pdBo = 4u * (pd0 + (64u + (u32)lane) % 6u);  // dword store 2 (lanes 0..31)
+  const u32 pbR = (u32)lane / 3u, pbK = (u32)lane % 3u;                                // byte store (lanes 0..47)
+  const u32 pbO = pbK < pnh ? psh + pbK : 4u * (pd0 + 6u) + (pbK - pnh);
   uint8_t *prov_frame = PROV ? p.prov_out + (size_t)frame * p.prov_fs : nullptr;
 
   int sb = 0;                  // ring slot of input row R0 and of blur row R0 - 2 (the rings advance together)
@@ -179,33 +209,34 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
   auto slot_off = [&](u32 k) -> u32 {  // k <= 19 + 19
     u32 t = (u32)sb + k;
     t = min(t, t - (u32)MX_RING);
-    return t * (u32)MX_PITCH;
+    return __umul24(t, (u32)MX_PITCH);
   };
 
   // ---- blur: input ring -> exact quotient -> blur ring; the undecidable pixels are queued ----------------------------------
-  // EDGE: the block touches the frame's right / top / bottom border (or is the run's warm-up): bytes outside the image are
-  // zero padding for the Sobel stage (cannyEdgeD.cu:142-149) and are never flagged
+  // EDGE: the block touches the frame's right / top / bottom border: bytes outside the image are zero padding for the Sobel
+  // stage (cannyEdgeD.cu:142-149) and are never flagged
   int fqn = 0;
-  auto blur_phase = [&](auto edge_c, int R0, bool warm) {
+  auto blur_phase = [&](auto edge_c, int R0) {
     constexpr bool EDGE = decltype(edge_c)::value;
     const int br = R0 + 2 + q;  // the lane's blur row
     const bool row_img = (u32)br < (u32)H;
-    const bool row_flag = row_img && (!warm || q >= 12);  // (the warm-up block only serves blur rows r0-2 .. r0+1)
-    const u32 wb = rowoff[4] + lcW;
+    const u32 wb = rowoff[4] + bbase + lcS;
+    u32 wc = rowoff[4] + bbase + lcC;
     const v16i zero16 = {};
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       v4i B[5];
 #pragma unroll
-      for (int i = 0; i < 5; ++i) B[i] = lds128(rowoff[i] + wbase + lcB + (u32)(64 * pp));
+      for (int i = 0; i < 5; ++i) B[i] = lds128(rowoff[i] + wbase + lcS + (u32)(64 * pp));
       v16i acc = mfma8(A[0], B[0], zero16);
       acc = mfma8(A[1], B[1], acc);
       acc = mfma8(A[2], B[2], acc);
       acc = mfma8(A[1], B[3], acc);
       acc = mfma8(A[0], B[4], acc);
       u32 w = 0;
+      v4i out;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
+      for (int g = 0; g < 4; ++g) {  // the lane's dword g: columns 16 kh + 4 g .. + 3 of the tile
         u32 P[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) P[j] = (u32)mad24(acc[4 * g + j], magic, c0);
@@ -216,26 +247,24 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
         u32 fm = g == 3 ? fm3 : 0x80808080u;
         if (pp == 0 && g == 0) { qd = (qd & m00) | (MX_PAD & ~m00); fm &= m00; }
         if constexpr (EDGE) {
-          const int col0 = s0 - 2 + 28 * (2 * pp + par) + 8 * g + 4 * kh;  // the group's first column
-          const int nv = min(max(W - col0, 0), 4);                       // its columns inside the image (col0 >= -2: handled above)
+          const int col0 = s0 - 2 + 28 * (2 * pp + par) + 16 * kh + 4 * g;  // the group's first column
+          const int nv = min(max(W - col0, 0), 4);                         // its columns inside the image (col0 >= -2: handled above)
           const u32 bm = row_img ? (nv >= 4 ? 0xFFFFFFFFu : (1u << (8 * nv)) - 1u) : 0u;
           qd = (qd & bm) | (MX_PAD & ~bm);
-          fm &= row_flag ? bm : 0u;
+          fm &= bm;
         }
         // zero-byte detector on the fraction bytes (a byte equal to 1 above a zero byte may be flagged too: harmless)
         w |= ((fd - 0x01010101u) & ~fd & fm) >> g;
-        if (g < 3) lds32(wb + (u32)(64 * pp + 8 * g)) = qd;
-        else if (kh == 0) lds32(wb + (u32)(64 * pp + 24)) = qd;
-        // the group that opens a segment is also bytes 28..31 of the segment before
-        if (g == 0 && kh == 0 && (pp > 0 || par == 1)) lds32(wb + (u32)(64 * pp) - 4u) = qd;
+        out[g] = (int)qd;
       }
-      // entry: bits 4..7 of byte j = groups 3..0 of column j; low nibble of byte 0 = q, of byte 1 = par, kh, pp
+      lds128(wb + (u32)(64 * pp)) = out;      // (dword 3 of the lanes kh = 1 is not a column of the tile: overwritten below)
+      lds32(wc) = (u32)out[0];                 // after it, in program order: the tail of the segment before
+      wc += lcCstep;
+      // entry: bits 4..7 of byte j = dwords 3..0 of column j; low nibble of byte 0 = q, of byte 1 = par, kh, pp
       const u64 any = __ballot(w != 0);
-      if (any) {
-        const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(any >> 32), __builtin_amdgcn_mbcnt_lo((u32)any, (u32)fqn));
-        if (w) lds32(xbase + 4u * rank) = w | (u32)q | ((u32)(lane >> 4) << 8) | ((u32)pp << 10);
-        fqn += __popcll(any);
-      }
+      const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(any >> 32), __builtin_amdgcn_mbcnt_lo((u32)any, (u32)fqn));
+      lds32(lane_sel(any, xbase + 4u * rank, dump)) = w | (u32)q | ((u32)(lane >> 4) << 8) | ((u32)pp << 10);
+      fqn += __popcll(any);
     }
   };
 
@@ -251,22 +280,31 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
       u32 ro[5];
 #pragma unroll
       for (int r = 0; r < 5; ++r) ro[r] = slot_off(eq + (u32)r);
+      const u32 segb = (u32)MX_SEG0 + 32u * t;
       while (fl) {
         const u32 b = (u32)__builtin_ctz(fl);
         fl &= fl - 1;
-        const u32 m = 8u * (7u - (b & 7u)) + 4u * ekh + (b >> 3);  // the pixel's column of the tile
-        u32 px[25];  // all 25 taps are requested before the first is used
+        const u32 o = 16u * ekh + 4u * (7u - (b & 7u)) + (b >> 3);  // the pixel's column of the tile: its taps are bytes o .. o + 4 of the segment
+        const u32 a0 = wbase + segb + (o & ~3u), sh = o & 3u, sh8 = 8u * sh;
+        u32 lo[5], hi[5];  // all 10 dwords are requested before the first is used
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
-#pragma unroll
-          for (int c = 0; c < 5; ++c) px[r * 5 + c] = smem[wbase + ro[r] + 32u * t + m + (u32)c];
+        for (int r = 0; r < 5; ++r) { lo[r] = lds32(a0 + ro[r]); hi[r] = lds32(a0 + ro[r] + 4u); }
         asm volatile("" ::: "memory");
         float f = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 25; ++i) f = __builtin_fmaf(GKC.v[i], (float)(px[i] ^ 0x80u), f);
+        for (int r = 0; r < 5; ++r) {
+          const u32 w0 = __builtin_amdgcn_alignbyte(hi[r], lo[r], sh) ^ MX_PAD;   // taps 0..3
+          const u32 w1 = (hi[r] >> sh8) ^ 0x80u;                                  // tap 4 (byte 0)
+          f = __builtin_fmaf(GKC.v[5 * r + 0], (float)(w0 & 0xFFu), f);
+          f = __builtin_fmaf(GKC.v[5 * r + 1], (float)((w0 >> 8) & 0xFFu), f);
+          f = __builtin_fmaf(GKC.v[5 * r + 2], (float)((w0 >> 16) & 0xFFu), f);
+          f = __builtin_fmaf(GKC.v[5 * r + 3], (float)(w0 >> 24), f);
+          f = __builtin_fmaf(GKC.v[5 * r + 4], (float)(w1 & 0xFFu), f);
+        }
         const unsigned char v = (unsigned char)((u32)(int)f ^ 0x80u);
-        smem[bbase + ro[4] + 32u * t + m] = v;
-        if (m < 4u && t >= 1u) smem[bbase + ro[4] + 32u * t - 4u + m] = v;
+        const u32 wa = bbase + ro[4] + segb + o;
+        smem[wa] = v;
+        if (o < 4u) smem[wa - 4u] = v;  // (tile 0: into the row's padding)
       }
     }
   };
@@ -275,13 +313,13 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
   auto nms_batch = [&](int nent, int R0) {
     wave_lds_sync();
     const bool live = lane < nent;  // the other lanes compute on stale ids and store nothing
-    const u32 id = lds16(xbase + 2u * ((u32)(qhead + lane) & (u32)(MX_NQ - 1)));  // bits 0..3 row, 4 tile parity, 5 half, 6..7 g, 8..9 pp
+    const u32 id = lds16(xbase + 2u * ((u32)(qhead + lane) & (u32)(MX_NQ - 1)));  // bits 0..3 row, 4 tile parity, 5 half, 6..7 dword, 8..9 pp
     const u32 eq = id & 15u, eh = (id >> 5) & 1u, eg = (id >> 6) & 3u, u = 2u * ((id >> 8) & 3u) + ((id >> 4) & 1u);
     const int row = R0 + (int)eq;
-    const u32 c4 = 7u * u + 2u * eg + eh;           // the group's index in the strip
+    const u32 c4 = 7u * u + 4u * eh + eg;           // the group's index in the strip
     const int col0 = s0 + 4 * (int)c4;              // column of the group's pixel 0
-    // blur rows row-2 .. row+2; window bytes 8 g + 4 h .. + 7 of segment u = pixels -2 .. 5
-    const u32 lo = bbase + 32u * u + 8u * eg + 4u * eh;
+    // blur rows row-2 .. row+2; window bytes 16 h + 4 g .. + 7 of segment u = pixels -2 .. 5
+    const u32 lo = bbase + (u32)MX_SEG0 + 32u * u + 16u * eh + 4u * eg;
     u32 d[5][3], s[5][3];  // per blur row: d = b[+1]-b[-1], s = b[-1]+2b[0]+b[+1] of the pixel pairs (-1,0), (1,2), (3,4)
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
@@ -358,26 +396,29 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
     px(std::integral_constant<int, 3>{}, A2[2], Um[2], Vp[2]);
     // (out-of-image pixels have S2 = 0: never candidates, a_lo >= 4)
     if (live) {
-      const u32 byte = c4 >> 1, sh = ((byte & 3u) << 3) + ((c4 & 1u) << 2);
+      const u32 byte = psh + (c4 >> 1), sh = ((byte & 3u) << 3) + ((c4 & 1u) << 2);
       const u32 ta = tbase + eq * 32u + (byte & ~3u);
       if (nibS) atomicOr(&lds32(ta), nibS << sh);
       if (nibC) atomicOr(&lds32(ta + 512u), nibC << sh);
-      if constexpr (PROV) *reinterpret_cast<gu32 *>(prov_frame + (u32)row * p.prov_pitch + (u32)col0) = nibble_to_bytes(nibS);
+      if constexpr (PROV && !(MX_ABL & 4)) *reinterpret_cast<gu32 *>(prov_frame + (u32)row * p.prov_pitch + (u32)col0) = nibble_to_bytes(nibS);
     }
     qhead = (qhead + nent) & (MX_NQ - 1);
     qcount -= nent;
   };
 
   // ---- Sobel: blur ring -> sumX, sumY -> which groups of 4 pixels may hold a candidate -> NMS batches ------------------------
+  // EDGE: some of the block's rows or columns are not this run's (the first block's rows above r0, rows from rend on, columns
+  // from W on)
   auto sobel_phase = [&](auto edge_c, int R0) {
     constexpr bool EDGE = decltype(edge_c)::value;
-    const bool row_ok = R0 + q < rend;
+    const bool row_ok = R0 + q >= r0 && R0 + q < rend;
     const v16i zero16 = {};
+    const u32 idl = (u32)lane;
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       v4i B[3];
 #pragma unroll
-      for (int i = 0; i < 3; ++i) B[i] = lds128(rowoff[1 + i] + bbase + lcB + (u32)(64 * pp));
+      for (int i = 0; i < 3; ++i) B[i] = lds128(rowoff[1 + i] + bbase + lcS + (u32)(64 * pp));
       v16i aX = mfma8(A[3], B[0], zero16);
       v16i aY = mfma8(A[5], B[0], zero16);
       aX = mfma8(A[4], B[1], aX);
@@ -394,58 +435,66 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
           T = mad24(aX[4 * g + j], aX[4 * g + j], T);
           T = mad24(aY[4 * g + j], aY[4 * g + j], T);
         }
-        u32 thr = (pp == 3 && g == 2) ? thr32 : (pp == 3 && g == 3) ? thr33 : a_lo0;
+        u32 thr = g == 3 ? thr3 : (pp == 3 && g >= 1) ? thr7 : a_lo0;
         if constexpr (EDGE) {
-          const int col0 = s0 + 28 * (2 * pp + par) + 8 * g + 4 * kh;
+          const int col0 = s0 + 28 * (2 * pp + par) + 16 * kh + 4 * g;
           thr = (row_ok && col0 < W) ? thr : 0xFFFFFFFFu;
         }
-        const bool pass = (u32)T >= thr;
-        const u64 mk = __ballot(pass);
-        if (mk) {
-          const u32 pos = ((u32)(qhead + qcount) + mbcnt64(mk)) & (u32)(MX_NQ - 1);
-          if (pass) lds16(xbase + 2u * pos) = (unsigned short)((u32)lane | ((u32)g << 6) | ((u32)pp << 8));
-          qcount += __popcll(mk);
-        }
+        const u64 mk = __ballot((u32)T >= thr);
+        const u32 pos = ((u32)(qhead + qcount) + mbcnt64(mk)) & (u32)(MX_NQ - 1);
+        lds16(lane_sel(mk, xbase + 2u * pos, dump)) = (unsigned short)(idl | ((u32)g << 6) | ((u32)pp << 8));
+        qcount += __popcll(mk);
       }
+      if (MX_ABL & 1) { qhead = (qhead + qcount) & (MX_NQ - 1); qcount = 0; }
       while (qcount >= 64) nms_batch(64, R0);
     }
     while (qcount > 0) nms_batch(min(qcount, 64), R0);
   };
 
-  // ---- the run: a warm-up block (blur rows r0-2 .. r0+1), then the blocks of output rows r0 + 16 b .. + 15 --------------------
-  u32 xr[MX_ROWS];
-#pragma unroll
-  for (int k = 0; k < MX_ROWS; ++k) xr[k] = load_row(r0 - 12 + k);
-  const int nblocks = (rend - r0 + MX_ROWS - 1) / MX_ROWS;
+  // ---- the run: blocks of output rows R0 .. R0+15, R0 = r0 - 4 + 16 b ------------------------------------------------------
+  const int nblocks = (rend - r0 + MX_LAG + MX_ROWS - 1) / MX_ROWS;
   const u32 prow = (u32)lane >> 2, ppart = (u32)lane & 3u;  // plane-tile / map-row stores: 4 lanes per row
+  u32 xr[MX_ROWS];
+  {  // input rows R0 .. R0+3 of the first block
+    u32 x0[MX_LAG];
+#pragma unroll
+    for (int k = 0; k < MX_LAG; ++k) x0[k] = load_row(r0 - MX_LAG + k);
+#pragma unroll
+    for (int k = 0; k < MX_ROWS; ++k) xr[k] = load_row(r0 + k);
+#pragma unroll
+    for (int k = 0; k < MX_LAG; ++k) {
+      const int row = r0 - MX_LAG + k;
+      const u32 m = (u32)row < (u32)H ? cmask : 0u;
+      lds32(wr1 + (u32)(k * MX_PITCH)) = (x0[k] & m) ^ MX_PAD;
+    }
+  }
 #pragma nounroll
-  for (int b = -1; b < nblocks; ++b) {
-    const int R0 = r0 + MX_ROWS * b;
-    const bool warm = b < 0;
+  for (int b = 0; b < nblocks; ++b) {
+    const int R0 = r0 - MX_LAG + MX_ROWS * b;
     // new input rows R0+4 .. R0+19
 #pragma unroll
     for (int k = 0; k < MX_ROWS; ++k) {
-      const int row = R0 + 4 + k;
+      const int row = R0 + MX_LAG + k;
       const u32 m = (u32)row < (u32)H ? cmask : 0u;  // rows above / below the image are zero padding (cannyEdgeD.cu:91-98)
-      const u32 x = (xr[k] & m) ^ MX_PAD;
-      u32 sl = (u32)sb + 4u + (u32)k;
+      u32 sl = (u32)sb + (u32)(MX_LAG + k);
       sl = sl >= (u32)MX_RING ? sl - (u32)MX_RING : sl;
-      lds32(wr1 + sl * (u32)MX_PITCH) = x;
-      lds32(wr2 + sl * (u32)MX_PITCH) = x;
+      lds32(wr1 + sl * (u32)MX_PITCH) = (xr[k] & m) ^ MX_PAD;
     }
     if (b + 1 < nblocks) {
 #pragma unroll
-      for (int k = 0; k < MX_ROWS; ++k) xr[k] = load_row(R0 + 20 + k);
+      for (int k = 0; k < MX_ROWS; ++k) xr[k] = load_row(R0 + MX_LAG + MX_ROWS + k);
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) rowoff[k] = slot_off((u32)(q + k));
     wave_lds_sync();
     fqn = 0;
-    const bool edge_rows = warm || R0 + 2 < 0 || R0 + 17 >= H;
-    if (edge_rows || edge_cols) blur_phase(std::true_type{}, R0, warm);
-    else blur_phase(std::false_type{}, R0, warm);
+    const bool edge_rows = R0 + 2 < 0 || R0 + 17 >= H;
+    if (!(MX_ABL & 16)) {
+      if (edge_rows || edge_cols) blur_phase(std::true_type{}, R0);
+      else blur_phase(std::false_type{}, R0);
+    }
     wave_lds_sync();
-    fixup();
+    if (!(MX_ABL & 2)) fixup();
     wave_lds_sync();
     if (p.dbg_blur) {  // diagnostics (HC_OPT_DEBUG_TAPS): the fixed-up blur rows of this run
       for (int k = 0; k < MX_ROWS; ++k) {
@@ -453,53 +502,62 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
         if (br < r0 || br >= rend) continue;
         for (int c = lane; c < MX_STRIP_W && s0 + c < W; c += 64) {
           const u32 y = (u32)c + 2u;
-          p.dbg_blur[(size_t)frame * p.dbg_fs + (size_t)br * p.dbg_pitch + (u32)(s0 + c)] = smem[bbase + slot_off(4u + (u32)k) + 32u * (y / 28u) + y % 28u] ^ 0x80u;
+          p.dbg_blur[(size_t)frame * p.dbg_fs + (size_t)br * p.dbg_pitch + (u32)(s0 + c)] = smem[bbase + slot_off(4u + (u32)k) + (u32)MX_SEG0 + 32u * (y / 28u) + y % 28u] ^ 0x80u;
         }
       }
     }
-    if (!warm) {
-      // zero the plane tiles (the fix-up queue is done with the space); the map rows of the block are stored as zeros now,
-      // the few groups with strong pixels are overwritten by the batches (stores of one wave to one address keep their order)
-      *reinterpret_cast<v4i *>(smem + tbase + 16u * (u32)lane) = v4i{ 0, 0, 0, 0 };
-      if constexpr (PROV) {
-        if (R0 + (int)prow < rend) {
-          uint8_t *pr = prov_frame + (u32)(R0 + (int)prow) * p.prov_pitch + (u32)s0;
-#pragma unroll
-          for (int k = 0; k < 7; ++k) {
-            const u32 i8 = ppart + 4u * (u32)k;  // 27 groups of 8 columns
-            if (i8 < 27u && s0 + 8 * (int)i8 < W) *reinterpret_cast<gu32x2 *>(pr + 8u * i8) = u32x2{ 0u, 0u };
-          }
-        }
-      }
-      wave_lds_sync();
-      const bool edge_out = R0 + MX_ROWS > rend || s0 + MX_STRIP_W > W;
-      if (edge_out) sobel_phase(std::true_type{}, R0);
-      else sobel_phase(std::false_type{}, R0);
-      wave_lds_sync();
-      // the block's plane bytes: 16 rows x 27 bytes per plane, 7 bytes per lane
-      if (R0 + (int)prow < rend) {
-        const u32 go = (u32)(R0 + (int)prow) * plane_pitch + (u32)(27 * strip);
+    // zero the plane tiles; the map rows of the block are stored as zeros now, the few groups with strong pixels are
+    // overwritten by the batches (stores of one wave to one address keep their order)
+    lds128(tbase + 16u * (u32)lane) = v4i{ 0, 0, 0, 0 };
+    const int orow = R0 + (int)prow;
+    const bool orow_ok = orow >= r0 && orow < rend;
+    if constexpr (PROV && !(MX_ABL & 4)) {
+      if (orow_ok) {
+        uint8_t *pr = prov_frame + (u32)orow * p.prov_pitch + (u32)s0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
-          const u32 bb = ppart * 7u + (u32)k;
-          if (bb < 27u && (u32)(27 * strip) + bb < plane_pitch) {
-            splane[go + bb] = smem[tbase + prow * 32u + bb];
-            cplane[go + bb] = smem[tbase + 512u + prow * 32u + bb];
-          }
+          const u32 i8 = ppart + 4u * (u32)k;  // 27 groups of 8 columns
+          if (i8 < 27u && s0 + 8 * (int)i8 < W) *reinterpret_cast<gu32x2 *>(pr + 8u * i8) = u32x2{ 0u, 0u };
         }
       }
-      wave_lds_sync();  // (the next block's fix-up queue overwrites the tiles)
     }
+    wave_lds_sync();
+    const bool edge_out = R0 < r0 || R0 + MX_ROWS > rend || s0 + MX_STRIP_W > W;
+    if (!(MX_ABL & 8)) {
+      if (edge_out) sobel_phase(std::true_type{}, R0);
+      else sobel_phase(std::false_type{}, R0);
+    }
+    wave_lds_sync();
+    // the block's plane bytes: 16 rows x 27 bytes per plane
+    if (!(MX_ABL & 4)) {
+      auto put32 = [&](u32 r, u32 o) {
+        const int row = R0 + (int)r;
+        if (row >= r0 && row < rend && pg0 + o < plane_pitch) {
+          const u32 go = (u32)row * plane_pitch + pg0 + o;
+          *reinterpret_cast<u32 *>(splane + go) = lds32(tbase + r * 32u + o);
+          *reinterpret_cast<u32 *>(cplane + go) = lds32(tbase + 512u + r * 32u + o);
+        }
+      };
+      put32(pdA, pdAo);
+      if (lane < 32) put32(pdB, pdBo);
+      const int row = R0 + (int)pbR;
+      if (lane < 48 && row >= r0 && row < rend && pg0 + pbO < plane_pitch) {
+        const u32 go = (u32)row * plane_pitch + pg0 + pbO;
+        splane[go] = smem[tbase + pbR * 32u + pbO];
+        cplane[go] = smem[tbase + 512u + pbR * 32u + pbO];
+      }
+    }
+    wave_lds_sync();  // (the next block's fix-up queue and input rows overwrite the queue and the dump dwords)
     sb = sb + MX_ROWS >= MX_RING ? sb + MX_ROWS - MX_RING : sb + MX_ROWS;
   }
 }
 
 size_t front_mx_lds_bytes() { return (size_t)4 * MX_WAVE_BYTES; }
 
-// Mode R, one-channel frames: strips of 216 columns, runs of 16 * blocks rows
+// Mode R, one-channel frames: strips of 216 columns, runs of p.run_rows rows (16 n - 4 rows cost n blocks)
 hipError_t launch_front_mx(const FrontParams &p, hipStream_t s)
 {
-  if (p.bgr || p.run_rows < MX_ROWS || p.run_rows % MX_ROWS != 0 || p.nchunks * p.run_rows < p.H) return hipErrorInvalidValue;
+  if (p.bgr || p.run_rows < 1 || (long)p.nchunks * p.run_rows < p.H) return hipErrorInvalidValue;
   if (p.nstrips != front_mx_strips(p.W) || (long)p.total_items != (long)p.nframes * p.nstrips * p.nchunks) return hipErrorInvalidValue;
   const size_t w4 = ((size_t)p.W + 3) / 4 * 4;
   if ((unsigned long long)p.H * p.in_pitch >= (1ull << 32) || p.in_pitch < w4) return hipErrorInvalidValue;

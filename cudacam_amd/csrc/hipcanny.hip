@@ -780,7 +780,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.dense_enter = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : c->dense_enter;
       fp.dense_leave = c->dense_mode == 0 ? 0x7FFFFFFF : c->dense_mode == 1 ? -1 : c->dense_leave;
       long waves_per_chunk = (long)n_out * fp.nstrips;
-      if (c->mode == HC_MODE_R && c->dump_region && c->half_mode != 0) {
+      if (c->mode == HC_MODE_R && c->dump_region && c->half_mode != 0 && !(c->mx_mode == 1 && fp.bgr == 0 && !c->per_channel)) {  // (HC_OPT_FRONT_MX 1 goes first)
         // HALF form (narrow frames): the (frame, 240-column half-strip) units of a run of rows are dealt to half-waves in
         // pairs -- 640 columns: 1.5 waves instead of 2 -- when that needs fewer waves and the lane offsets fit
         const long per = c->per_channel ? 3 : 1, nh = front8_half_strips(W), pairs = ((long)n * nh + 1) / 2;
@@ -813,20 +813,30 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
       fp.total_items = (int)(waves_per_chunk * fp.nchunks);
       // k_front_mx (blur and Sobel on the matrix pipe): one-channel frames of Mode R whose runs fill the chip -- its blocks
-      // are 16 rows by 216 columns and every run repeats a 16-row warm-up, so small batches stay with k_front8
+      // are 16 rows by 216 columns: small batches stay with k_front8
       use_mx = c->mode == HC_MODE_R && form == 2 && fp.bgr == 0 && !fp.half && c->mx_mode != 0 && (unsigned long long)H * sp < (1ull << 32)
                && sp >= round_up((size_t)W, 4) && (!s.prov || W % 8 == 0)
                && (c->mx_mode == 1 || (!c->chunk && (long long)n_out * W * H >= 120ll * 1000 * 1000));
       if (use_mx) {
         fp.nstrips = front_mx_strips(W);
         const long units = (long)n_out * fp.nstrips;
-        // runs of about 8 blocks (128 rows) that tile the frame evenly; shorter while the chip (3072 resident waves) is not full
-        const int blocks_h = (H + 15) / 16;
-        long nch = std::max<long>(1, (blocks_h + 4) / 8);
+        // a run of n blocks covers 16 n - 4 rows and costs about one block more to start (workgroup launch, prologue: 0.2 ms
+        // of a 1024-frame launch in runs of 124 rows, profiles/r04/mx_ablation.txt): the run count that needs the fewest
+        // blocks in all, among those that give every wave slot of the chip (3072) six runs or more where the frame allows
+        long nch;
         if (c->chunk) nch = std::max<long>(1, (H + c->chunk - 1) / c->chunk);
-        else if (units * nch < 3072) nch = std::min<long>((3072 + units - 1) / units, blocks_h);
-        const int blocks = (int)((blocks_h + nch - 1) / nch);
-        fp.run_rows = front_mx_run_rows(blocks);
+        else {
+          const long hi = std::max<long>(1, (H + 11) / 12);
+          const long lo = std::min<long>(hi, std::max<long>(1, (6 * 3072 + units - 1) / units));
+          long best = -1, best_cost = 0;
+          for (long k = lo; k <= std::min<long>(hi, lo + 24); ++k) {
+            const long rows = (H + k - 1) / k, runs = (H + rows - 1) / rows, last = H - rows * (runs - 1);
+            const long cost = ((rows + 4 + 15) / 16 + 1) * (runs - 1) + (last + 4 + 15) / 16 + 1;
+            if (best < 0 || cost < best_cost) { best = k; best_cost = cost; }
+          }
+          nch = best;
+        }
+        fp.run_rows = (int)((H + nch - 1) / nch);
         fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
         fp.total_items = (int)(units * fp.nchunks);
         c->last_front_form = 5;

@@ -127,6 +127,7 @@ def test_mx_automatic_for_big_batches(oracle, w):
     d_out = [torch.zeros((nb, h, w), dtype=torch.uint8, device="cuda") for _ in range(3)]
     with api.Context(w, h, 1, nb) as ctx:
         ctx.set_option(api.OPT_PIPELINE, 1)
+        ctx.set_option(api.OPT_FRONT_HALF, 0)   # (640 columns: the half-strip form of k_front8 would go first)
         for mode, form in ((-1, 5), (0, 2)):
             ctx.set_option(api.OPT_FRONT_MX, mode)
             for r in range(5):
