@@ -120,15 +120,16 @@ static __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul2
 static __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 static __device__ __forceinline__ v16i mfma8(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
 
-template <bool PROV>
-__global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
+// WPB: waves per workgroup (independent waves; 1: a retiring wave's slot and LDS are free for the next one at once)
+template <bool PROV, int WPB>
+__global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
 {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wib = threadIdx.x >> 6;
   // the run's hysteresis flag words, zeroed by the first workgroups on their way in (as k_front8)
   for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < p.zero_count; i += gridDim.x * blockDim.x) p.zero_words[i] = 0u;
-  const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + wib);
+  const int item = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPB + wib);
   if (item >= p.total_items) return;
   const int chunk = item % p.nchunks;
   const int strip = (item / p.nchunks) % p.nstrips;
@@ -223,20 +224,28 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
     const u32 wb = rowoff[4] + bbase + lcS;
     u32 wc = rowoff[4] + bbase + lcC;
     const v16i zero16 = {};
-#pragma unroll
-    for (int pp = 0; pp < 4; ++pp) {
-      v4i B[5];
+    // The MFMAs of group pp + 1 are issued one by one between the four parts of the vector code that finishes group pp (a
+    // dependent MFMA chain issues one every 32 cycles, 8 of them the wave's own; alone in a row the five of a group stall the
+    // wave for 160 cycles and the first reader of the sums for 64 more).  sched_barrier pins that order.
+    v4i B[5];
+    auto reads = [&](int pp) {
 #pragma unroll
       for (int i = 0; i < 5; ++i) B[i] = lds128(rowoff[i] + wbase + lcS + (u32)(64 * pp));
-      v16i acc = mfma8(A[0], B[0], zero16);
-      acc = mfma8(A[1], B[1], acc);
-      acc = mfma8(A[2], B[2], acc);
-      acc = mfma8(A[1], B[3], acc);
-      acc = mfma8(A[0], B[4], acc);
+    };
+    reads(0);
+    v16i acc = mfma8(A[0], B[0], zero16), nxt = zero16;
+    acc = mfma8(A[1], B[1], acc);
+    acc = mfma8(A[2], B[2], acc);
+    acc = mfma8(A[1], B[3], acc);
+    acc = mfma8(A[0], B[4], acc);
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      if (pp < 3) reads(pp + 1);
       u32 w = 0;
       v4i out;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // the lane's dword g: columns 16 kh + 4 g .. + 3 of the tile
+        __builtin_amdgcn_sched_barrier(0);
         u32 P[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) P[j] = (u32)mad24(acc[4 * g + j], magic, c0);
@@ -256,7 +265,15 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
         // zero-byte detector on the fraction bytes (a byte equal to 1 above a zero byte may be flagged too: harmless)
         w |= ((fd - 0x01010101u) & ~fd & fm) >> g;
         out[g] = (int)qd;
+        __builtin_amdgcn_sched_barrier(0);
+        if (pp < 3) {  // (the reads were issued a part ago)
+          if (g == 0) nxt = mfma8(A[0], B[0], zero16);
+          else if (g == 1) nxt = mfma8(A[1], B[1], nxt);
+          else if (g == 2) nxt = mfma8(A[2], B[2], nxt);
+          else nxt = mfma8(A[1], B[3], nxt);
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
       lds128(wb + (u32)(64 * pp)) = out;      // (dword 3 of the lanes kh = 1 is not a column of the tile: overwritten below)
       lds32(wc) = (u32)out[0];                 // after it, in program order: the tail of the segment before
       wc += lcCstep;
@@ -265,6 +282,8 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
       const u32 rank = __builtin_amdgcn_mbcnt_hi((u32)(any >> 32), __builtin_amdgcn_mbcnt_lo((u32)any, (u32)fqn));
       lds32(lane_sel(any, xbase + 4u * rank, dump)) = w | (u32)q | ((u32)(lane >> 4) << 8) | ((u32)pp << 10);
       fqn += __popcll(any);
+      __builtin_amdgcn_sched_barrier(0);
+      if (pp < 3) acc = mfma8(A[0], B[4], nxt);
     }
   };
 
@@ -414,6 +433,9 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
     const bool row_ok = R0 + q >= r0 && R0 + q < rend;
     const v16i zero16 = {};
     const u32 idl = (u32)lane;
+    // (the blur stage's order -- the next group's MFMAs between the parts of this group's vector code -- needs a second pair of
+    //  sums alive across the batches here: 17 to 42 registers spilled, 2.8 ms instead of 1.8; with the A operands fetched again
+    //  per stage to make room: no spills, 2.06 ms.  profiles/r04/mx_experiments.md)
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
       v4i B[3];
@@ -422,19 +444,16 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
       v16i aX = mfma8(A[3], B[0], zero16);
       v16i aY = mfma8(A[5], B[0], zero16);
       aX = mfma8(A[4], B[1], aX);
-      aX = mfma8(A[3], B[2], aX);
       aY = mfma8(A[6], B[2], aY);
+      aX = mfma8(A[3], B[2], aX);
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        // S2 = sumX^2 + sumY^2 (the reference's float gradient is a strictly increasing function of it, k_front8); summed over
-        // the group: at least any of the four -- a necessary condition, the batch decides exactly
-        int T = mul24(aX[4 * g], aX[4 * g]);
-        T = mad24(aY[4 * g], aY[4 * g], T);
+        // S2 = sumX^2 + sumY^2 (the reference's float gradient is a strictly increasing function of it, k_front8): the largest
+        // of the group's four against the low threshold -- the batch decides the rest (their sum, 3 instructions cheaper,
+        // queued enough groups for nothing to cost 2 % more in the batches)
+        int T = mad24(aY[4 * g], aY[4 * g], mul24(aX[4 * g], aX[4 * g]));
 #pragma unroll
-        for (int j = 1; j < 4; ++j) {
-          T = mad24(aX[4 * g + j], aX[4 * g + j], T);
-          T = mad24(aY[4 * g + j], aY[4 * g + j], T);
-        }
+        for (int j = 1; j < 4; ++j) T = max(T, mad24(aY[4 * g + j], aY[4 * g + j], mul24(aX[4 * g + j], aX[4 * g + j])));
         u32 thr = g == 3 ? thr3 : (pp == 3 && g >= 1) ? thr7 : a_lo0;
         if constexpr (EDGE) {
           const int col0 = s0 + 28 * (2 * pp + par) + 16 * kh + 4 * g;
@@ -552,7 +571,7 @@ __global__ __launch_bounds__(256, 3) void k_front_mx(const FrontParams p)
   }
 }
 
-size_t front_mx_lds_bytes() { return (size_t)4 * MX_WAVE_BYTES; }
+size_t front_mx_lds_bytes(int wpb) { return (size_t)wpb * MX_WAVE_BYTES; }
 
 // Mode R, one-channel frames: strips of 216 columns, runs of p.run_rows rows (16 n - 4 rows cost n blocks)
 hipError_t launch_front_mx(const FrontParams &p, hipStream_t s)
@@ -563,10 +582,16 @@ hipError_t launch_front_mx(const FrontParams &p, hipStream_t s)
   if ((unsigned long long)p.H * p.in_pitch >= (1ull << 32) || p.in_pitch < w4) return hipErrorInvalidValue;
   if (p.prov_out && (p.W % 8 != 0)) return hipErrorInvalidValue;
   if (p.dbg_blur && p.dbg_pitch < (u32)p.W) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)((p.total_items + 3) / 4)), block(256);
-  const size_t lds = front_mx_lds_bytes();
-  if (p.prov_out) hipLaunchKernelGGL((k_front_mx<true>), grid, block, lds, s, p);
-  else hipLaunchKernelGGL((k_front_mx<false>), grid, block, lds, s, p);
+  const int wpb = p.one_wave ? 1 : 4;
+  const dim3 grid((unsigned)((p.total_items + wpb - 1) / wpb)), block(64 * wpb);
+  const size_t lds = front_mx_lds_bytes(wpb);
+  if (p.prov_out) {
+    if (wpb == 1) hipLaunchKernelGGL((k_front_mx<true, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_front_mx<true, 4>), grid, block, lds, s, p);
+  } else {
+    if (wpb == 1) hipLaunchKernelGGL((k_front_mx<false, 1>), grid, block, lds, s, p);
+    else hipLaunchKernelGGL((k_front_mx<false, 4>), grid, block, lds, s, p);
+  }
   return hipGetLastError();
 }
 

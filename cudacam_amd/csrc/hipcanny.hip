@@ -119,7 +119,7 @@ struct hc_ctx {
   int l2gradient = 0;   // Mode O: cv::Canny's L2gradient flag
   int half_mode = -1;   // HC_OPT_FRONT_HALF: -1 automatic, 0 never, 1 whenever the buffers allow it
   int dense_mode = -1;  // HC_OPT_FRONT_DENSE: -1 automatic, 0 never, 1 every window
-  int mx_mode = -1;     // HC_OPT_FRONT_MX: -1 automatic (big batches of one-channel frames), 0 never, 1 whenever the run allows it
+  int mx_mode = 0;      // HC_OPT_FRONT_MX: 1 = k_front_mx whenever the run allows it (opt-in: include/hipcanny.h)
   uint8_t *d_dump = nullptr;    // k_front8's dump areas (FrontParams::dump / dump_c / dump_p), followed by its page of zeros (FrontParams::zeros)
   size_t dump_region = 0;       // 0: the plain layout (16 KiB + 32 KiB); otherwise four regions of this size (the HALF form's lane offsets reach a frame further)
   uint8_t *d_bplane = nullptr;  // split mode: u8 blur plane between the two kernels (lazy)
@@ -812,11 +812,9 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       fp.run_rows = front8_run_rows(windows);
       fp.nchunks = (H + fp.run_rows - 1) / fp.run_rows;
       fp.total_items = (int)(waves_per_chunk * fp.nchunks);
-      // k_front_mx (blur and Sobel on the matrix pipe): one-channel frames of Mode R whose runs fill the chip -- its blocks
-      // are 16 rows by 216 columns: small batches stay with k_front8
-      use_mx = c->mode == HC_MODE_R && form == 2 && fp.bgr == 0 && !fp.half && c->mx_mode != 0 && (unsigned long long)H * sp < (1ull << 32)
-               && sp >= round_up((size_t)W, 4) && (!s.prov || W % 8 == 0)
-               && (c->mx_mode == 1 || (!c->chunk && (long long)n_out * W * H >= 120ll * 1000 * 1000));
+      // k_front_mx (blur and Sobel on the matrix pipe): one-channel frames of Mode R, on request (HC_OPT_FRONT_MX)
+      use_mx = c->mode == HC_MODE_R && form == 2 && fp.bgr == 0 && !fp.half && c->mx_mode == 1 && (unsigned long long)H * sp < (1ull << 32)
+               && sp >= round_up((size_t)W, 4) && (!s.prov || W % 8 == 0);
       if (use_mx) {
         fp.nstrips = front_mx_strips(W);
         const long units = (long)n_out * fp.nstrips;
@@ -885,7 +883,11 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
         const bool auto_one = c->nslot_use < NSLOT ? c->front_one : (long long)n_out * W * H >= 120ll * 1000 * 1000;
         fp.one_wave = (s.prov && !c->per_channel && (c->front_wpb_mode == 1 || (c->front_wpb_mode < 0 && auto_one))) ? 1 : 0;
         c->last_front_waves = c->per_channel ? 3 : fp.one_wave ? 1 : 4;
-        if (use_mx) { c->last_front_waves = 4; HIPCK(launch_front_mx(fp, sf)); }
+        if (use_mx) {  // (its waves are independent too: HC_OPT_FRONT_WPB 1 / 0 picks one-wave / four-wave workgroups)
+          fp.one_wave = c->front_wpb_mode == 1 ? 1 : 0;
+          c->last_front_waves = fp.one_wave ? 1 : 4;
+          HIPCK(launch_front_mx(fp, sf));
+        }
         else HIPCK(launch_front8(fp, sf));
         HIPCK(mark(sf, b_mono | B_GAUSS | B_GRAD | B_NMS | B_THR, hc_ctx::K_FRONT_B));
       }
@@ -1163,7 +1165,7 @@ int hc_set_option(hc_ctx *c, int option, int value)
     if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_DENSE: -1 (automatic), 0 (never) or 1 (every window)");
     c->dense_mode = value;
   } else if (option == HC_OPT_FRONT_MX) {
-    if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_MX: -1 (automatic), 0 (never) or 1 (whenever possible)");
+    if (value != 0 && value != 1) return fail(HC_E_ARG, "HC_OPT_FRONT_MX: 0 (never) or 1 (whenever the run allows it)");
     c->mx_mode = value;
   } else if (option == HC_OPT_FRONT_HALF) {
     if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_HALF: -1 (automatic), 0 (never) or 1 (whenever possible)");

@@ -37,7 +37,7 @@ for i in range(cases):
         # round 3: the forms of k_front8 -- half-strip form and dense path: automatic, never, always
         opts["half"] = int(rng.choice([-1, -1, 0, 1, 1])); opts["dense"] = int(rng.choice([-1, -1, 0, 1]))
         # round 4: k_front_mx (blur and Sobel as i8 MFMAs) forced on in a third of the cases (it only takes one-channel k_front8 runs)
-        opts["mx"] = int(rng.choice([-1, 0, 1]))
+        opts["mx"] = int(rng.choice([0, 0, 1]))
         want = np.stack([O.canny_r(f, low, high, saturate=bool(opts["sat"])) for f in frames])
     else:
         opts["l2"] = int(rng.integers(0, 2)); opts["split"] = int(rng.choice([2, 2, 0])); opts["chunk"] = int(rng.choice([0, 2, 8, 9, 24, 50, 122, 400]))   # split: 2 k_front8o, 0 k_front_o

@@ -3,8 +3,7 @@ v_mfma_i32_32x32x32_i8 (strips of 216 columns, blocks of 16 rows, LDS rings of 3
 (HC_OPT_FRONT_MX = 1) and checked like the other forms: the fast path's own blur (hc_debug_tap: every byte the matrix
 pipe and the fix-up produced) and bit planes, and the final maps, against the oracle, bit for bit -- every tap-test
 image (borders, flat frames, the wrap bands, 1 x 1), widths around the strip and tile boundaries, run lengths,
-thresholds, the saturating variant, batches, pipelined mode with the provisional map, and the automatic choice for
-runs of 0.12 G pixels and more."""
+thresholds, the saturating variant, batches, pipelined mode with the provisional map, big batches, one-wave workgroups."""
 import numpy as np
 import pytest
 
@@ -114,9 +113,9 @@ def test_mx_pipelined_device_buffers(oracle):
 
 
 @pytest.mark.parametrize("w", [640, 1920])
-def test_mx_automatic_for_big_batches(oracle, w):
-    """Runs of 0.12 G pixels and more take k_front_mx by themselves (pipelined, three output buffers in turn); the maps are
-    those of k_front8."""
+def test_mx_big_batches_and_default(oracle, w):
+    """Runs of 0.13 G pixels (pipelined, three output buffers in turn, long runs of rows): k_front_mx on request, k_front8
+    by default; the maps are the same."""
     import torch
     h = 120
     nb = 130_000_000 // (w * h) + 1
@@ -128,8 +127,9 @@ def test_mx_automatic_for_big_batches(oracle, w):
     with api.Context(w, h, 1, nb) as ctx:
         ctx.set_option(api.OPT_PIPELINE, 1)
         ctx.set_option(api.OPT_FRONT_HALF, 0)   # (640 columns: the half-strip form of k_front8 would go first)
-        for mode, form in ((-1, 5), (0, 2)):
-            ctx.set_option(api.OPT_FRONT_MX, mode)
+        for mode, form in ((None, 2), (1, 5), (0, 2)):
+            if mode is not None:
+                ctx.set_option(api.OPT_FRONT_MX, mode)
             for r in range(5):
                 ctx.run_device(d_in.data_ptr(), w, w * h, d_out[r % 3].data_ptr(), w, w * h, nb)
             ctx.sync()
@@ -140,3 +140,17 @@ def test_mx_automatic_for_big_batches(oracle, w):
                     if not np.array_equal(got[f], want[f % 6]):
                         _diff(got[f], want[f % 6], f"{w}x{h}, HC_OPT_FRONT_MX {mode}, buffer {r}, frame {f}")
                 d_out[r].zero_()
+
+
+@pytest.mark.parametrize("wpb", [1, 4])
+def test_mx_waves_per_workgroup(oracle, wpb):
+    """One-wave and four-wave workgroups (HC_OPT_FRONT_WPB) compute the same maps."""
+    w, h, n = 1296, 300, 4
+    frames = _frames(w, h, n, 77)
+    with api.Context(w, h, 1, n) as ctx:
+        ctx.set_option(api.OPT_FRONT_MX, 1)
+        ctx.set_option(api.OPT_FRONT_WPB, wpb)
+        ctx.set_option(api.OPT_DEBUG_TAPS, 1)
+        got = ctx.process(frames)
+        _check(oracle, ctx, frames, got, tag=f"{wpb} waves per workgroup")
+        assert ctx.front_waves_per_workgroup() == wpb

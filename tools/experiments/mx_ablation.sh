@@ -3,10 +3,10 @@
 # kernel time alone (--no-pipeline) on the natural batch.  Usage: tools/experiments/mx_ablation.sh [-a "<bench args>"] <N> <N> ...
 set -uo pipefail
 R="${GRAFT_REPO_ROOT:-$(pwd)}"
-extra=""
+extra="--no-pipeline"
 if [ "${1:-}" = "-a" ]; then extra="$2"; shift 2; fi
 for v in "$@"; do
   export HIPCANNY_LIB="$R/cudacam_amd/exp/libhipcanny_abl$v.so"
   echo "== MX_ABL=$v $extra"
-  bash "$R/tools/kstats.sh" --mx always --rotate 1 --no-host-fed --no-pipeline $extra 2>&1 | grep front_mx
+  bash "$R/tools/kstats.sh" --mx always --rotate 1 --no-host-fed $extra 2>&1 | grep front
 done
