@@ -32,6 +32,7 @@ HBM_MEASURED_COPY_GBPS = 6290.0
 
 
 # hc_last_run_info's front form -> (config name, kernel name)
+CLOCK_WARMUP_S = 0.6   # untimed steps until the GPU has been busy this long (clock ramp-up of a process that starts on an idle GPU)
 FORM_NAME = {5: ("front-mx", "k_front_mx"), 2: ("front8", "k_front8"), 4: ("front8-half", "k_front8 (half-strip form)"), 1: ("split", "k_blur+k_nms"), 0: ("fused4", "k_front"), 3: ("k_front8o", "k_front8o"), -1: ("k_front_o", "k_front_o")}
 
 
@@ -192,7 +193,25 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
         nstep[0] += 1
         ctx.run_device(src.data_ptr(), W * C, W * C * H, o.data_ptr(), W, W * H, B, api.CannyStage.HYSTER)
 
+    # Untimed, before the W warm-up steps: steps until the GPU has been busy for CLOCK_WARMUP_S -- a process that starts on
+    # an idle MI355X runs its first ~100 ms of kernels at a fraction of the clock (a 28-step run from idle measured 5.4 ms
+    # per step against 2.5 ms once the clocks are up, tools/experiments/clock_probe.sh) -- and, with a content rotation, as
+    # many more as it takes for the timed region to begin with the rotation's first batch, after at least one whole rotation
+    # (so that `value` does not depend on where the warm-up ended; with --steps a multiple of the rotation every content
+    # is timed equally often).
+    clock_steps = 0
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < CLOCK_WARMUP_S:
+        for _ in range(4):
+            step()
+        ctx.sync()
+        clock_steps += 4
     for _ in range(a.warmup):
+        step()
+    align_steps = (-nstep[0]) % rot if rot > 1 else 0
+    if rot > 1 and nstep[0] + align_steps < 2 * rot:
+        align_steps += rot
+    for _ in range(align_steps):
         step()
     ctx.sync()
     torch.cuda.synchronize(dev)
@@ -261,6 +280,8 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
             "n_gpus": world,
             "steps": steps,
             "warmup": a.warmup,
+            "warmup_untimed_extra": {"clock_steps": clock_steps, "clock_warmup_s": CLOCK_WARMUP_S, "rotation_alignment_steps": align_steps,
+                                     "note": "untimed steps before / after the W warm-up steps: until the clocks are up, and so that the timed region starts with the rotation's first batch"},
             "ms_per_step": round(elapsed / steps * 1e3, 4),
             "ms_per_frame": round(elapsed / (steps * B) * 1e3, 6),
             # per-step times on the device clock: end-of-step to end-of-step hipEvent intervals (rank 0), SURVEY 8d "median and p10/p90"
@@ -290,7 +311,7 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
             # `continued` = runs of the whole timed region that needed the host-side continuation (each one stalls the stream)
             "hysteresis": {"launches_with_work": work_launches, "continued": h_continued, "runs": h_runs,
                            "launches_with_work_mean": round(h_work / max(h_runs, 1), 2), "launches_queued_mean": round(h_queued / max(h_runs, 1), 2)},
-            "by_content": _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch),
+            "by_content": _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch, steps),
             "by_content_note": ("step_ms = device-side interval between the completion of the previous run and of this one (front kernel + this "
                                 "run's hysteresis tail - the previous run's); kernel_ms = this content's front kernel, which runs BESIDE THE "
                                 "PREVIOUS content's hysteresis (noise: 3.9 ms after a natural batch, 5.0 ms after another noise batch)") if rot > 1 else None,
@@ -329,11 +350,13 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     ctx.close()
 
 
-def _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch):
+def _by_content(kinds, first_timed, intervals, front_each, B, alg_bytes_per_launch, steps):
     """Per content kind: the steps that processed it (interval j ends with timed step j + 1), their median step time and
     the front kernel's mean time on that content."""
     if len(kinds) == 1:
         return None
+    if len(front_each) != steps:
+        return None   # the library keeps the timestamps of the last 255 runs between two syncs: with more steps than that the samples no longer line up with the steps
     out = {}
     for ki, kind in enumerate(kinds):
         st = [intervals[j] for j in range(len(intervals)) if (first_timed + j + 1) % len(kinds) == ki]
@@ -361,7 +384,7 @@ def host_fed(a, d_in):
     (include/cvp/frameIO.hpp).  Bounded: about a second of work."""
     import ctypes as C
     lib = api.load_library()
-    nb = min(32, d_in.shape[0])   # 64 MiB of 1080p frames per batch: below that the hand-over between copies and kernels shows (tools/pcie_raw2.hip)
+    nb = min(32, d_in.shape[0])   # 64 MiB of 1080p frames per batch: below that the hand-over between copies and kernels shows (tools/experiments/pcie_raw2.hip)
     ch = a.channels
     frame_in, frame_out = W * H * ch, W * H * (3 if a.per_channel else 1)
     host_frames = d_in[:nb].cpu().numpy()

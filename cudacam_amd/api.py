@@ -51,6 +51,7 @@ OPT_COPY_STREAMS = 9
 OPT_PIPELINE_SLOTS = 10
 OPT_FRONT_WPB = 11
 OPT_FRONT_MX = 12
+OPT_TEST_HYST_LATE_GRID, OPT_TEST_HYST_LOOP, OPT_TEST_HYST_DIAG, OPT_TEST_HYST_GEOM, OPT_TEST_DENSE_ENTER, OPT_TEST_DENSE_LEAVE = 100, 101, 102, 103, 104, 105   # test / diagnostic hooks
 TAP_BLUR, TAP_THRESH = 1, 2
 
 # every symbol include/hipcanny.h declares

@@ -47,13 +47,8 @@ constexpr int F8_RING = F8_SUB + 4;                // rows kept in each LDS ring
 constexpr int F8_FQ = 128;                         // flagged-pixel queue entries per window (expected fill ~20); [F8_FQ] is a dump slot
 constexpr int F8_NQ = 512;                         // NMS queue (ids), circular; [F8_NQ] is a dump slot
 constexpr int F8_ROW_BYTES = 64 * 8;
-#ifndef F8_WPB
-#define F8_WPB 4  // waves per workgroup of k_front8 (mono / BGR; per-channel mode: 3, one per channel).  The waves are independent.
-#endif
-#ifndef F8_LDS_PAD
-#define F8_LDS_PAD 0  // experiments: extra LDS per wave (occupancy studies)
-#endif
-constexpr int F8_WAVE_BYTES = 2 * F8_RING * F8_ROW_BYTES + (F8_FQ + 4) * 4 + (F8_NQ + 4) * 4 + F8_LDS_PAD;  // 12,832 B: 3 workgroups of 4 waves per CU
+constexpr int F8_WPB = 4;                          // waves per workgroup of k_front8 (mono / BGR; one-wave form: 1; per-channel mode: 3, one per channel).  The waves are independent.
+constexpr int F8_WAVE_BYTES = 2 * F8_RING * F8_ROW_BYTES + (F8_FQ + 4) * 4 + (F8_NQ + 4) * 4;  // 12,832 B: 3 workgroups of 4 waves per CU
 
 int front8_run_rows(int windows) { return F8_SUB * windows - 4; }
 int front8_strips(int W) { return (W + F8_STRIP_W - 1) / F8_STRIP_W; }
@@ -708,9 +703,6 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
   // frames that never take the path).  A window that queued more than p.dense_enter half-lanes hands over to the dense
   // loop, a dense window that counted fewer than p.dense_leave hands back.
   int w = 0;
-#ifdef F8_NO_DENSE
-  for (; w < nwin; ++w) window(std::false_type{}, w);
-#else
   bool dense = p.dense_enter < 0;  // HC_OPT_FRONT_DENSE = 1: every window (tests)
   while (w < nwin) {
 #pragma nounroll
@@ -724,7 +716,6 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
       dense = wq > p.dense_leave;
     }
   }
-#endif
 }
 
 

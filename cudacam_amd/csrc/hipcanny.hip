@@ -86,9 +86,7 @@ struct hc_ctx {
   Slot slot[NSLOT];
   int nslot_use = 2;  // slots the pipelined runs rotate through (4 for small batches)
   int dense_enter = 512, dense_leave = 384;  // HC_DENSE_ENTER / HC_DENSE_LEAVE (experiments)
-  int hyst_force_lists = -1;  // HC_HYST_LISTS = 1 / 0: worklists from launch 1 on always / never (experiments)
-  int hyst_mixed_from = 2;  // first launch of a mixed-schedule run that works from lists (HC_HYST_MIXED_FROM: experiments)
-  int pipe_slots = 0;  // experiments (HC_PIPE_SLOTS = 2 .. 4): that many slots whatever the batch size
+  int pipe_slots = 0;  // HC_OPT_PIPELINE_SLOTS 2 / 3: that many slots whatever the batch size (0: by the rule)
   // timestamps of the last pipelined runs, by run number & 7: front kernel finished / hysteresis finished (watch_chain)
   hipEvent_t ring_f[8] = {}, ring_d[8] = {};
   unsigned long long ring_seq[8] = {};
@@ -109,9 +107,8 @@ struct hc_ctx {
   u32 wl_prev[MAX_HYST_LAUNCHES + 1] = { 0 };  // worklist lengths of the last finished run's launches
   size_t wl_prev_tiles = 0;                    // ... and its tile count (0: none / not a wide-frame run)
   bool hyst_lists_last = false;        // the last run used the worklist scheme
-  int hyst_late_grid = 0;              // diagnostics (HC_HYST_LATE_GRID): workgroups of the hysteresis launches >= 1
-  int hyst_list_floor = 2048;          // smallest grid of a list launch (HC_HYST_LIST_FLOOR)
-  bool hyst_loop = true;               // small runs: one looping hysteresis launch (HC_HYST_LOOP=0 turns it off)
+  int hyst_late_grid = 0;              // tests (HC_OPT_TEST_HYST_LATE_GRID): workgroups of the hysteresis launches >= 1
+  bool hyst_loop = true;               // small runs: one looping hysteresis launch (HC_OPT_TEST_HYST_LOOP 0 turns it off)
   int hyst_obs[3] = { 0, 0, 0 };       // hysteresis launches the last runs needed with base_waves << i waves per workgroup (0: not seen)
   int hyst_obs_base = 0, hyst_obs_rows = 0;  // the base shape those observations belong to
   bool split_set = false;  // HC_OPT_FRONT_SPLIT was set by the caller
@@ -145,6 +142,7 @@ struct hc_ctx {
   int last_slot = 0;          // slot of the most recent fused run
   // hc_download_begin .. hc_download_end
   uint8_t *dl_host = nullptr; size_t dl_row = 0, dl_fs = 0; int dl_n = 0;
+  bool dl_stale = false;  // a host-side hysteresis continuation rewrote maps after hc_download_begin queued their copy (whichever entry point ran it)
   // HC_OPT_COPY_STREAMS: uploads / downloads on the device's shared copy streams, tied to the context stream by events
   bool copy_streams = false;
   hipEvent_t ev_up = nullptr, ev_ready = nullptr, ev_ready2 = nullptr, ev_down = nullptr;
@@ -217,8 +215,8 @@ int alloc_slot_parts(hc_ctx *c, Slot &s)
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     HIPCK(hipStreamCreateWithPriority(&s.s_hyst, hipStreamNonBlocking, greatest));
   }
-  HIPCK(hipEventCreate(&s.ev_front));  // (with timestamps: finish_slot compares the end of a run's hysteresis with the end of the next front kernel)
-  HIPCK(hipEventCreate(&s.ev_done));
+  HIPCK(hipEventCreateWithFlags(&s.ev_front, hipEventDisableTiming));  // (cross-stream waits only: the timestamps watch_chain compares are ring_f / ring_d)
+  HIPCK(hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming));
   return HC_OK;
 }
 
@@ -441,6 +439,7 @@ int finish_slot(hc_ctx *c, Slot &s)
   }
   c->last_continued = 1;
   c->hyst_totals[1] += 1;
+  if (c->dl_host) c->dl_stale = true;
   for (int round = 0; round < 1000000; ++round) {
     HIPCK(hipMemsetAsync(s.d_flags, 0, sizeof(u32) * (FLAG_WORDS + WL_COUNT_WORDS + 2 * s.ph.wl_stride), st));  // flags, worklist counts and reasons
     HystParams hp = s.ph;
@@ -549,7 +548,6 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // (BGR frames blended into grey: 25 launches, 205 -> 222 k frames/s; the 16 launches of 1080p grey frames fit inside
   // the front kernel's time, and there the lists cost 2 %).
   if (c->hyst_late_grid) hp.lists = c->hyst_late_grid > 0;
-  else if (c->hyst_force_lists >= 0) hp.lists = c->hyst_force_lists;
   else if (hp.npanels > 1) hp.lists = !(c->wl_prev_tiles == hp.wl_stride && (size_t)c->wl_prev[1] * 5 > hp.wl_stride * 3);
   else hp.lists = c->last_work_launches >= 20 || (c->hyst_lists_last && c->last_work_launches >= 14);
   c->hyst_lists_last = hp.lists != 0;
@@ -560,7 +558,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
   // few long edges through the frame (launch 2 still starts every tile, and writes the first list): 1080p grey 394 -> 405 k
   // frames/s, 256 frames per run 307 -> 317 k; with the lists from launch 1 on: 400 k, from launch 4: 404 k.  (The list
   // streams above keep their lists from launch 1: BGR 259 against 252 k, 8K x 3 8.76 against 8.64 k; 4K would gain 2 %.)
-  int mixed_from = (!hp.lists && !c->hyst_late_grid && small_tiles) ? c->hyst_mixed_from : 0;
+  int mixed_from = (!hp.lists && !c->hyst_late_grid && small_tiles) ? 2 : 0;  // first launch of a mixed-schedule run that works from lists
   // A small run (a few frames): all K rounds in one launch, device-wide barriers between them (k_hyst_loop) -- K host
   // calls and K trips through the command processor fewer per run; a run it cannot finish (its workgroups not resident
   // together, or more rounds needed than queued) is continued by finish_slot like any other.
@@ -582,7 +580,7 @@ int queue_hyst_expand(hc_ctx *c, Slot &s, hipStream_t st, uint8_t *out, size_t o
     // a run, launch_hyst's schedule by the tile count
     hp.late_grid = c->hyst_late_grid > 0 ? c->hyst_late_grid : 0;
     if (mixed_from > 0) hp.lists = k < mixed_from ? 0 : k == mixed_from ? 2 : 1;
-    if (hp.lists == 1 && !hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>((size_t)c->hyst_list_floor, 2 * (size_t)c->wl_prev[k] + 256));
+    if (hp.lists == 1 && !hp.late_grid && k > 0 && c->wl_prev_tiles == hp.wl_stride) hp.late_grid = (int)std::min<size_t>(hp.wl_stride, std::max<size_t>((size_t)2048, 2 * (size_t)c->wl_prev[k] + 256));
     // diagnostics cost ~3 same-address atomics per wave (hundreds of microseconds per launch): opt-in only
     hp.stats = c->hyst_diag ? s.d_flags + MAX_HYST_LAUNCHES + 3 * k : nullptr;
     HIPCK(launch_hyst(hp, st));
@@ -879,7 +877,7 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
       {
         // one-wave workgroups: pipelined big batches with the provisional map, mono / BGR (the per-channel form is three waves, one per channel)
         // (small batches, whose four chains overlap anyway: from 0.12 G pixels per run -- 64 frames of 1080p +3.5 %, 128 frames
-        //  +4.5 %; 4 to 32 frames -3 to -6 %: tools/exp_small_wpb.sh)
+        //  +4.5 %; 4 to 32 frames -3 to -6 %: tools/experiments/exp_small_wpb.sh)
         const bool auto_one = c->nslot_use < NSLOT ? c->front_one : (long long)n_out * W * H >= 120ll * 1000 * 1000;
         fp.one_wave = (s.prov && !c->per_channel && (c->front_wpb_mode == 1 || (c->front_wpb_mode < 0 && auto_one))) ? 1 : 0;
         c->last_front_waves = c->per_channel ? 3 : fp.one_wave ? 1 : 4;
@@ -1013,19 +1011,6 @@ hc_ctx *hc_create(int device, int width, int height, int channels, int max_batch
   };
   bool good = ok(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking), "hipStreamCreate");
   c->stream = c->own_stream;
-  c->hyst_diag = getenv("HC_HYST_DIAG") != nullptr;
-  if (const char *e = getenv("HC_HYST_LATE_GRID")) c->hyst_late_grid = std::max(-1, atoi(e));  // tests: tiny grids exercise the hand-on of worklist entries
-  if (const char *e = getenv("HC_HYST_LOOP")) c->hyst_loop = atoi(e) != 0;
-  if (const char *e = getenv("HC_DENSE_ENTER")) c->dense_enter = std::max(0, atoi(e));
-  if (const char *e = getenv("HC_DENSE_LEAVE")) c->dense_leave = std::max(0, atoi(e));
-  if (const char *e = getenv("HC_HYST_LISTS")) c->hyst_force_lists = atoi(e) != 0;
-  if (const char *e = getenv("HC_HYST_MIXED_FROM")) c->hyst_mixed_from = std::min(8, std::max(1, atoi(e)));
-  if (const char *e = getenv("HC_PIPE_SLOTS")) c->pipe_slots = std::min(NSLOT, std::max(0, atoi(e))) == 1 ? 2 : std::min(NSLOT, std::max(0, atoi(e)));
-  if (const char *e = getenv("HC_HYST_LIST_FLOOR")) c->hyst_list_floor = std::max(1, atoi(e));
-  if (const char *e = getenv("HC_HYST_GEOM")) {
-    int tr = 0, wv = 0;
-    if (sscanf(e, "%dx%d", &tr, &wv) == 2) c->hyst_geom = tr * 100 + wv;
-  }
   // (a BGR row is read in 12-byte groups of 4 pixels: keep room for the ragged last group)
   good = good && alloc_frames(&c->d_in, &c->in_pitch, &c->in_fs, round_up((size_t)width, 8) * channels, height, max_batch, (size_t)width * channels) == HC_OK;
   good = good && alloc_frames(&c->d_out, &c->out_pitch, &c->out_fs, (size_t)width, height, max_batch, (size_t)width) == HC_OK;
@@ -1167,6 +1152,18 @@ int hc_set_option(hc_ctx *c, int option, int value)
   } else if (option == HC_OPT_FRONT_MX) {
     if (value != 0 && value != 1) return fail(HC_E_ARG, "HC_OPT_FRONT_MX: 0 (never) or 1 (whenever the run allows it)");
     c->mx_mode = value;
+  } else if (option == HC_OPT_TEST_HYST_LATE_GRID) {  // tests: tiny grids exercise the hand-on of worklist entries
+    c->hyst_late_grid = std::max(-1, value);
+  } else if (option == HC_OPT_TEST_HYST_LOOP) {
+    c->hyst_loop = value != 0;
+  } else if (option == HC_OPT_TEST_HYST_DIAG) {
+    c->hyst_diag = value != 0;
+  } else if (option == HC_OPT_TEST_HYST_GEOM) {  // rows per wave x 100 + waves per workgroup; 0: by the rule
+    c->hyst_geom = std::max(0, value);
+  } else if (option == HC_OPT_TEST_DENSE_ENTER) {
+    c->dense_enter = std::max(0, value);
+  } else if (option == HC_OPT_TEST_DENSE_LEAVE) {
+    c->dense_leave = std::max(0, value);
   } else if (option == HC_OPT_FRONT_HALF) {
     if (value < -1 || value > 1) return fail(HC_E_ARG, "HC_OPT_FRONT_HALF: -1 (automatic), 0 (never) or 1 (whenever possible)");
     HIPCK(hipSetDevice(c->device));
@@ -1358,6 +1355,7 @@ int hc_download_begin(hc_ctx *c, uint8_t *host, size_t row_stride, size_t frame_
   Slot &s = c->slot[c->last_slot];
   if (s.pending && s.stream != c->stream) HIPCK(hipStreamWaitEvent(c->stream, s.ev_done, 0));
   c->dl_host = host; c->dl_row = row_stride; c->dl_fs = frame_stride; c->dl_n = n;
+  c->dl_stale = false;
   if (int rc = queue_download(c)) { c->dl_host = nullptr; return rc; }
   return HC_OK;
 }
@@ -1367,9 +1365,11 @@ int hc_download_end(hc_ctx *c)
   if (!c) return fail(HC_E_ARG, "null context");
   if (!c->dl_host) return fail(HC_E_STATE, "hc_download_end without hc_download_begin");
   HIPCK(hipSetDevice(c->device));
-  const unsigned long long continued_before = c->hyst_totals[1];
   int rc = finish_all(c);  // convergence of every run in flight; the host-side continuation if one needed it
-  if (rc == HC_OK && c->hyst_totals[1] != continued_before) rc = queue_download(c);  // the maps changed after the copy was queued
+  // the maps changed after the copy was queued -- here, or in any entry point that finished the runs since hc_download_begin
+  // (hc_upload, hc_sync, hc_set_option, hc_hysteresis_totals ...): copy them again
+  if (rc == HC_OK && c->dl_stale) rc = queue_download(c);
+  c->dl_stale = false;
   if (rc == HC_OK && (c->copy_streams ? hipEventSynchronize(c->ev_down) : hipStreamSynchronize(c->stream)) != hipSuccess) rc = fail(HC_E_HIP, "waiting for the download failed");
   c->dl_host = nullptr;
   return rc;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(HC_FRONT_WA
     const u32 p3 = pair_shift(Ar, B);  // (x3, x4)
     // NB: every packed u16 sum below stays < 2^16 per half (S <= 40545), so plain 32-bit adds and
     // subtractions act on both halves at once without carry/borrow between them -- and v_add_u32 /
-    // v_sub_u32 issue at twice the rate of the v_pk_* forms on gfx950 (tools/valu_rate2.hip).
+    // v_sub_u32 issue at twice the rate of the v_pk_* forms on gfx950 (tools/experiments/valu_rate2.hip).
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const u32 P = h == 0 ? Bl + B : A + Ar;

@@ -231,7 +231,7 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * device, one for device -> host -- tied to the context stream by events, instead of on the context stream itself.
  * Copies that share a stream with kernels do not overlap across contexts on this runtime (three contexts, 32 MiB
  * batches: 28 GB/s each way; with the two copy streams 40, with 64 MiB batches 47 of the 48 GB/s the link carries both
- * ways at once -- tools/pcie_raw2.hip).
+ * ways at once -- tools/experiments/pcie_raw2.hip).
  *
  * HC_OPT_FRONT_WPB (default -1 = automatic, Mode R, mono / BGR input): waves per workgroup of k_front8 in pipelined big
  * batches.  One-wave workgroups refill a retiring wave's slot at once and gain the front kernel 2-3 % beside the
@@ -254,7 +254,12 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * batch before (2.4-2.55 against 2.5 ms), and half as much again on frames full of candidates (iid noise: 7.7 against
  * 5.1 ms), for which it has no dense path. */
 enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6, HC_OPT_FRONT_HALF = 7,
-       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9, HC_OPT_PIPELINE_SLOTS = 10, HC_OPT_FRONT_WPB = 11, HC_OPT_FRONT_MX = 12 };
+       HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9, HC_OPT_PIPELINE_SLOTS = 10, HC_OPT_FRONT_WPB = 11, HC_OPT_FRONT_MX = 12,
+       /* test and diagnostic hooks (the library reads no environment variables): hysteresis launches >= 1 on a fixed grid with
+        * worklists (-1: lists, default grid); the looping hysteresis launch of small runs off (0) / on; per-launch statistics for
+        * tools/hyst_diag.py; hysteresis workgroup shape (rows x 100 + waves, 0 = by the rule); k_front8's dense-path thresholds */
+       HC_OPT_TEST_HYST_LATE_GRID = 100, HC_OPT_TEST_HYST_LOOP = 101, HC_OPT_TEST_HYST_DIAG = 102, HC_OPT_TEST_HYST_GEOM = 103,
+       HC_OPT_TEST_DENSE_ENTER = 104, HC_OPT_TEST_DENSE_LEAVE = 105 };
 int hc_set_option(hc_ctx *ctx, int option, int value);
 
 /* The fast path's own intermediates of the last HC_STAGE_HYSTER run (HC_OPT_DEBUG_TAPS must have been set before it),

@@ -392,19 +392,19 @@ def test_pipelined_runs(oracle, w, h, mode):
 
 @pytest.mark.parametrize("w", [4500, 900])
 @pytest.mark.parametrize("grid", ["1", "3"])
-def test_hysteresis_worklists_with_tiny_grids(oracle, grid, w, monkeypatch):
+def test_hysteresis_worklists_with_tiny_grids(oracle, grid, w):
     """The worklist form of the hysteresis (frames wider than one 2048-column panel; one-panel streams that need 20
     launches or more): launches >= 1 take their tiles from lists, one entry per workgroup; entries beyond the grid are
-    handed on to the next launch.  HC_HYST_LATE_GRID (read by hc_create) forces the lists and grids of 1 and 3
+    handed on to the next launch.  HC_OPT_TEST_HYST_LATE_GRID forces the lists and grids of 1 and 3
     workgroups, so nearly every entry of every launch takes that road -- serpentine chains that cross panel seams and
     row tiles, plain and pipelined, must still reach the exact fixpoint (through the host-side continuation when the
     queued launches run out)."""
     import torch
-    monkeypatch.setenv("HC_HYST_LATE_GRID", grid)
     h, nb = 200, 2
     frames = np.stack([synth.serpentine(w, h, amp=20, seed_amp=120), synth.natural(w, h, 77)])
     want = oracle.canny_r_batch(frames, 10, 40, threads=4)
     with api.Context(w, h, 1, nb) as ctx:
+        ctx.set_option(api.OPT_TEST_HYST_LATE_GRID, int(grid))
         got = ctx.process(frames)
         for f in range(nb):
             _diff(got[f], want[f], f"tiny late grid {grid}, frame {f}")
@@ -771,6 +771,41 @@ def test_download_begin_end(oracle):
                 assert lib.hc_download_end(ctx.handle) != 0   # nothing in flight
                 if launches == 1:
                     assert ctx.hysteresis_totals()[1] == 2, "the one-launch runs were not continued from the host"
+    finally:
+        lib.hc_host_free(C.c_void_p(hout))
+
+
+@pytest.mark.parametrize("between", ["sync", "totals", "upload"])
+def test_download_end_after_a_continuation_elsewhere(oracle, between):
+    """A host-side continuation that another entry point performs between hc_download_begin and hc_download_end (every one
+    that finishes the runs in flight does: hc_sync, hc_hysteresis_totals -- which may also reset the counter --, hc_upload)
+    rewrites maps whose copy is already queued: hc_download_end must copy them again (round-3 advisor finding)."""
+    lib = api.load_library()
+    w, h = 1000, 2300
+    line = np.zeros((h, w), np.uint8)
+    line[:, 100:140] = 20
+    for r in range(20):
+        line[r, 100:140] = 120 - 5 * r
+    frames = np.stack([line, synth.natural(w, h, 79)])
+    want = oracle.canny_r_batch(frames, 10, 40, threads=4)
+    hout = lib.hc_host_alloc(2 * w * h)
+    try:
+        with api.Context(w, h, 1, 2) as ctx:
+            ctx.set_tuning(0, 1)   # one launch queued, a frame that needs 18: continued from the host
+            ctx.hysteresis_totals(reset=True)
+            ctx.upload(frames)
+            ctx.run(api.CannyStage.HYSTER, 2)
+            api._ck(lib.hc_download_begin(ctx.handle, C.c_void_p(hout), w, w * h, 2))
+            if between == "sync":
+                ctx.sync()
+            elif between == "totals":
+                assert ctx.hysteresis_totals(reset=True)[1] == 1, "the one-launch run was not continued from the host"
+            else:
+                ctx.upload(frames)
+            api._ck(lib.hc_download_end(ctx.handle))
+            got = np.ctypeslib.as_array((C.c_uint8 * (2 * w * h)).from_address(hout)).reshape(2, h, w)
+            for f in range(2):
+                _diff(got[f], want[f], f"download_begin, hc_{between}, download_end: frame {f}")
     finally:
         lib.hc_host_free(C.c_void_p(hout))
 

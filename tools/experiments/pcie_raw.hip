@@ -1,5 +1,5 @@
 // Raw PCIe rates of the GPU box, page-locked host memory: H2D alone, D2H alone, both at once on two streams -- the
-// ceiling for bench.py's host_fed leg and tools/stream_bench.  hipcc tools/pcie_raw.hip -o tools/bin/pcie_raw
+// ceiling for bench.py's host_fed leg and tools/stream_bench.  hipcc tools/experiments/pcie_raw.hip -o tools/bin/pcie_raw
 #include <hip/hip_runtime.h>
 #include <chrono>
 #include <cstdio>

@@ -1,5 +1,5 @@
 // Micro-benchmark: sustained issue rate of the VALU instruction classes k_front uses, per SIMD,
-// at 1/2/4/8 waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate
+// at 1/2/4/8 waves per SIMD.  Build: hipcc --offload-arch=gfx950 -O3 tools/experiments/valu_rate.hip -o /tmp/valu_rate
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #define REP8(x) x x x x x x x x

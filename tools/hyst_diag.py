@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostics: sweeps / active tiles per hysteresis launch on the bench workload."""
 import sys, os, time
-os.environ['HC_HYST_DIAG'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from cudacam_amd import api, synth
 api.preload_hip_runtime()
@@ -13,6 +12,7 @@ uniq = synth.frames("natural", W, H, 8)
 d_in = torch.from_numpy(uniq).cuda().repeat(B // 8, 1, 1).contiguous()
 d_out = torch.empty_like(d_in)
 ctx = api.Context(W, H, 1, B)
+ctx.set_option(api.OPT_TEST_HYST_DIAG, 1)
 ctx.set_tuning(0, K)
 ctx.run_device(d_in.data_ptr(), W, W * H, d_out.data_ptr(), W, W * H, B)
 ctx.sync()

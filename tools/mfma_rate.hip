@@ -7,7 +7,7 @@
 //      cycles per iteration per SIMD against the same n instructions without the MFMA -- the model the front kernel needs
 //      (does the MFMA hide behind the wave's own vector work, and what does it take from the issue port);
 //   4. MFMA-only waves and VALU-only waves as partners on one SIMD (512-thread workgroups, waves 0-3 matrix, 4-7 vector).
-// Timing: wall clock (hipEvents) over a launch that fills the chip, as tools/valu_rate*.hip do; cycles at 2.4 GHz.
+// Timing: wall clock (hipEvents) over a launch that fills the chip, as tools/experiments/valu_rate*.hip do; cycles at 2.4 GHz.
 // Build: hipcc --offload-arch=gfx950 -O3 -o mfma_rate tools/mfma_rate.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
