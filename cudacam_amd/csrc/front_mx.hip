@@ -84,38 +84,25 @@ typedef u32x2 __attribute__((aligned(4))) gu32x2;
 // output column o = 16 ((m >> 2) & 1) + 4 (m >> 3) + (m & 3) of the tile (so that register v of a lane is column 16 kh + v)
 // from the window's columns o .. o + 4; rows with o >= 28 are zero (28 outputs per 32-column window).
 //   0..2  Gaussian kernel rows 0 / 4, 1 / 3, 2      3, 4  Sobel X, blur rows -1 / +1 and blur row 0      5, 6  Sobel Y, row -1 / row +1
-//   7..10 the Sobel matrices of the DENSE stage: row m produces the gradient at window position 1 + 14 ((m >> 2) & 1) +
-//         4 (m >> 3) + (m & 3), so that register v of a lane is window position 1 + 14 kh + v: 16 adjacent columns per lane, the
-//         two halves of a tile overlapping by two -- every lane holds both horizontal neighbours of its 14 inner columns
 struct alignas(16) MxATable {
-  u32 v[11][64][4];
+  u32 v[7][64][4];
   constexpr MxATable() : v{}
   {
     constexpr int KR[3][5] = { { 2, 4, 5, 4, 2 }, { 4, 9, 12, 9, 4 }, { 5, 12, 15, 12, 5 } };
     for (int l = 0; l < 64; ++l) {
       const int m = l % 32, kh = l / 32;
       const int o = 16 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
-      const int pd = 1 + 14 * ((m >> 2) & 1) + 4 * (m >> 3) + (m & 3);
       for (int dd = 0; dd < 4; ++dd)
         for (int jj = 0; jj < 4; ++jj) {
-          const int k = 16 * kh + 4 * dd + jj;  // window column
-          const int t = k - o;                  // tap: window column - output column
-          for (int a = 0; a < 11; ++a) {
+          const int t = 16 * kh + 4 * dd + jj - o;  // tap: window column - output column
+          for (int a = 0; a < 7; ++a) {
             int c = 0;
-            if (a < 7) {
-              if (o < 28) {
-                if (a < 3) c = (t >= 0 && t <= 4) ? KR[a][t] : 0;
-                else if (a == 3) c = t == 1 ? -1 : t == 3 ? 1 : 0;                  // - left + right   (cannyEdgeD.cu:158-162)
-                else if (a == 4) c = t == 1 ? -2 : t == 3 ? 2 : 0;
-                else if (a == 5) c = (t == 1 || t == 3) ? 1 : t == 2 ? 2 : 0;       // row above, +      (:163-167)
-                else c = (t == 1 || t == 3) ? -1 : t == 2 ? -2 : 0;                 // row below, -
-              }
-            } else {
-              const int td = k - pd;  // -1, 0, +1: left, centre, right
-              if (a == 7) c = td == -1 ? -1 : td == 1 ? 1 : 0;
-              else if (a == 8) c = td == -1 ? -2 : td == 1 ? 2 : 0;
-              else if (a == 9) c = (td == -1 || td == 1) ? 1 : td == 0 ? 2 : 0;
-              else c = (td == -1 || td == 1) ? -1 : td == 0 ? -2 : 0;
+            if (o < 28) {
+              if (a < 3) c = (t >= 0 && t <= 4) ? KR[a][t] : 0;
+              else if (a == 3) c = t == 1 ? -1 : t == 3 ? 1 : 0;                  // - left + right   (cannyEdgeD.cu:158-162)
+              else if (a == 4) c = t == 1 ? -2 : t == 3 ? 2 : 0;
+              else if (a == 5) c = (t == 1 || t == 3) ? 1 : t == 2 ? 2 : 0;       // row above, +      (:163-167)
+              else c = (t == 1 || t == 3) ? -1 : t == 2 ? -2 : 0;                 // row below, -
             }
             v[a][l][dd] |= (u32)(c & 0xFF) << (8 * jj);
           }
@@ -132,107 +119,6 @@ __device__ const MxATable MX_A{};
 static __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
 static __device__ __forceinline__ int mul24(int a, int b) { return __mul24(a, b); }
 static __device__ __forceinline__ v16i mfma8(v4i a, v4i b, v16i c) { return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0); }
-// value held by the lane of image row q - 1 / q + 1 of the same tile half (q = lane % 16: a DPP row); 0 at the row's ends
-static __device__ __forceinline__ u32 from_row_above(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true); }  // row_shr:1
-static __device__ __forceinline__ u32 from_row_below(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x101, 0xF, 0xF, true); }  // row_shl:1
-
-// ---- the DENSE Sobel / NMS stage of a block: a block full of candidates (iid noise: every group) -------------------------------
-// The queue costs 5 vector instructions per queued group and recomputes every gradient it needs from blur bytes.  Here the
-// MFMAs' own sums are used: with the matrices 7..10 a lane holds sumX, sumY of 16 ADJACENT columns of its row (window
-// positions 1 + 14 kh + v), i.e. both horizontal neighbours of its 14 inner columns; the rows above and below are the
-// neighbouring lanes of the DPP row (q = lane % 16).  Per inner pixel: S2, the direction bins, the four neighbour maxima, one
-// select chain, the non-strict comparison and the two thresholds (the arithmetic of the batch), 14 bits per lane and plane
-// OR-ed into the plane tile.  Rows q = 0 and q = 15 are left to the caller.
-// A function of its own, NOT inlined: it keeps 48 sums and squares alive at once, and as part of the kernel's body it made the
-// register allocator spill values that live across the whole block loop (scratch traffic in the blur stage of every block, of
-// sparse frames too).  As a callee it saves and restores what it needs when it is called.
-// Returns the number of (lane, MFMA group) pairs that hold a pixel above the low threshold (0 .. 224).
-typedef __attribute__((address_space(3))) unsigned char *mx_lds_ptr;
-struct MxDenseArgs {
-  u32 bbase, tbase, lcS, ro1, ro2, ro3, psh, a_lo0, a_lo1, a_lo2, a_hi0, a_hi1, a_hi2, wrap_limit;
-  int s0, W, H, r0, rend, R0, edge;
-};
-static __device__ __attribute__((noinline)) int mx_dense_stage(mx_lds_ptr smem, const MxDenseArgs a)
-{
-  const int lane = threadIdx.x & 63;
-  const int q = lane & 15, par = (lane >> 4) & 1, kh = lane >> 5;
-  auto lds32 = [&](u32 off) -> __attribute__((address_space(3))) u32 & { return *reinterpret_cast<__attribute__((address_space(3))) u32 *>(smem + off); };
-  v4i A[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) A[i] = *reinterpret_cast<const v4i *>(MX_A.v[7 + i][lane]);
-  const int row = a.R0 + q;
-  const bool row_img = (u32)row < (u32)a.H;
-  const bool row_ok = q >= 1 && q <= 14 && row >= a.r0 && row < a.rend;
-  const v16i zero16 = {};
-  int dcount = 0;
-  auto group = [&](auto wrap_c, int pp, const v16i &aX, const v16i &aY, const u32 (&S)[16]) {
-    constexpr bool WRAP = decltype(wrap_c)::value;
-    const int colb = a.s0 + 28 * (2 * pp + par) - 1 + 14 * kh;  // column of register 0
-    u32 bS = 0, bC = 0, anyc = 0;
-    u32 Uc = from_row_above(S[15]), Dc = from_row_below(S[15]), Ub = from_row_above(S[14]), Db = from_row_below(S[14]), Ua, Da;  // (c: v + 1, b: v, a: v - 1)
-#pragma unroll
-    for (int v = 14; v >= 1; --v) {
-      Ua = from_row_above(S[v - 1]); Da = from_row_below(S[v - 1]);
-      const u32 g = S[v];
-      bool cand = g >= a.a_lo0, strong = g >= a.a_hi0;
-      if constexpr (WRAP) {  // u8 wrap of gradients >= 256 (cannyEdgeD.cu:267): the bands of S2 whose low byte passes the thresholds
-        const bool w0 = g >= 262144u, w1 = g >= 1048576u;
-        cand = (cand && !w0) || (g >= a.a_lo1 && !w1) || g >= a.a_lo2;
-        strong = (strong && !w0) || (g >= a.a_hi1 && !w1) || g >= a.a_hi2;
-      }
-      // direction bins (cannyEdgeD.cu:239-264) without atan2: E1 = 2x(x-y) - S2 > 0, E2 = 2x(x+y) - S2 > 0
-      const int x = aX[v], y = aY[v], x2 = x + x;
-      const bool p1 = mul24(x2, x - y) > (int)g, p2 = mul24(x2, x + y) > (int)g;
-      // neighbours (:245-264): bin0 down/up, bin1 down-left/up-right, bin2 right/left, bin3 up-left/down-right
-      const u32 n0 = max(Db, Ub), n1 = max(Da, Uc), n2 = max(S[v + 1], S[v - 1]), n3 = max(Ua, Dc);
-      const u32 mb = p1 ? (p2 ? n2 : n3) : (p2 ? n1 : n0);
-      const bool keep = mb <= g;  // non-strict on both sides, as the reference
-      bS = shift_in(bS, __ballot(strong && keep));
-      bC = shift_in(bC, __ballot(cand && keep));
-      anyc |= cand ? 1u : 0u;
-      Uc = Ub; Dc = Db; Ub = Ua; Db = Da;
-    }
-    // bit j of bS / bC = inner column j = column colb + 1 + j; columns beyond the strip's 216 or the image, rows that are not
-    // this stage's to decide: nothing
-    const int nv = min(min(a.W, a.s0 + MX_STRIP_W) - (colb + 1), 14);
-    const u32 vm = (row_ok && nv > 0) ? (1u << nv) - 1u : 0u;
-    bS &= vm; bC &= vm;
-    dcount += __popcll(__ballot(anyc != 0 && vm != 0));
-    const u32 pos = 8u * a.psh + (u32)(28 * (2 * pp + par) + 14 * kh), sh = pos & 31u;
-    const u32 ta = a.tbase + (u32)q * 32u + ((pos >> 5) << 2);
-    const u64 wS = (u64)bS << sh, wC = (u64)bC << sh;
-    auto lds_or = [&](u32 off, u32 bits) { if (bits) (void)__atomic_fetch_or(&lds32(off), bits, __ATOMIC_RELAXED); };
-    lds_or(ta, (u32)wS); lds_or(ta + 4u, (u32)(wS >> 32));
-    lds_or(ta + 512u, (u32)wC); lds_or(ta + 516u, (u32)(wC >> 32));
-  };
-#pragma nounroll
-  for (int pp = 0; pp < 4; ++pp) {
-    const u32 bo = a.bbase + a.lcS + (u32)(64 * pp);
-    const v4i B0 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>(smem + a.ro1 + bo);
-    const v4i B1 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>(smem + a.ro2 + bo);
-    const v4i B2 = *reinterpret_cast<__attribute__((address_space(3))) const v4i *>(smem + a.ro3 + bo);
-    v16i aX = mfma8(A[0], B0, zero16);
-    v16i aY = mfma8(A[2], B0, zero16);
-    aX = mfma8(A[1], B1, aX);
-    aY = mfma8(A[3], B2, aY);
-    aX = mfma8(A[0], B2, aX);
-    u32 S[16];
-    u32 gm = 0;
-#pragma unroll
-    for (int v = 0; v < 16; ++v) {
-      if (a.edge) {  // zero padding of the gradient stage (cannyEdgeD.cu:142-149, 222-229): no gradient outside the image
-        const int col = a.s0 + 28 * (2 * pp + par) - 1 + 14 * kh + v;
-        const bool in = row_img && (u32)col < (u32)a.W;
-        aX[v] = in ? aX[v] : 0; aY[v] = in ? aY[v] : 0;
-      }
-      S[v] = (u32)mad24(aY[v], aY[v], mul24(aX[v], aX[v]));
-      gm = max(gm, S[v]);
-    }
-    if (__ballot(gm >= a.wrap_limit) != 0) group(std::true_type{}, pp, aX, aY, S);
-    else group(std::false_type{}, pp, aX, aY, S);
-  }
-  return dcount;
-}
 
 // WPB: waves per workgroup (independent waves; 1: a retiring wave's slot and LDS are free for the next one at once)
 template <bool PROV, int WPB>
@@ -321,7 +207,6 @@ __global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
   int sb = 0;                  // ring slot of input row R0 and of blur row R0 - 2 (the rings advance together)
   u32 rowoff[5];               // byte offset of ring row (sb + q + k) mod 20, k = 0..4
   int qhead = 0, qcount = 0;   // NMS queue (wave-uniform)
-  int ecount = 0;              // groups the sparse Sobel stage queued in this block (the measure that starts the dense mode)
   auto slot_off = [&](u32 k) -> u32 {  // k <= 19 + 19
     u32 t = (u32)sb + k;
     t = min(t, t - (u32)MX_RING);
@@ -578,7 +463,6 @@ __global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
         const u32 pos = ((u32)(qhead + qcount) + mbcnt64(mk)) & (u32)(MX_NQ - 1);
         lds16(lane_sel(mk, xbase + 2u * pos, dump)) = (unsigned short)(idl | ((u32)g << 6) | ((u32)pp << 8));
         qcount += __popcll(mk);
-        ecount += __popcll(mk);
       }
       if (MX_ABL & 1) { qhead = (qhead + qcount) & (MX_NQ - 1); qcount = 0; }
       while (qcount >= 64) nms_batch(64, R0);
@@ -586,37 +470,6 @@ __global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
     while (qcount > 0) nms_batch(min(qcount, 64), R0);
   };
 
-  // ---- the DENSE stage (mx_dense_stage above), then rows q = 0 and q = 15 of the block: a neighbour row of theirs is in another
-  // block, so every group of the strip in them goes to the batches (ids as the sparse stage's: row, tile parity, half, dword, pp)
-  auto dense_phase = [&](bool edge, int R0) -> int {
-    MxDenseArgs da;
-    da.bbase = bbase; da.tbase = tbase; da.lcS = lcS; da.ro1 = rowoff[1]; da.ro2 = rowoff[2]; da.ro3 = rowoff[3]; da.psh = psh;
-    da.a_lo0 = a_lo0; da.a_lo1 = p.a_lo[1]; da.a_lo2 = p.a_lo[2]; da.a_hi0 = a_hi0; da.a_hi1 = p.a_hi[1]; da.a_hi2 = p.a_hi[2]; da.wrap_limit = wrap_limit;
-    da.s0 = s0; da.W = W; da.H = H; da.r0 = r0; da.rend = rend; da.R0 = R0; da.edge = edge;
-    const int dc = mx_dense_stage((mx_lds_ptr)smem, da);
-    const u32 c4 = (u32)lane, u = c4 / 7u, rem = c4 - 7u * u;
-    const u32 id0 = ((u & 1u) << 4) | ((rem >> 2) << 5) | ((rem & 3u) << 6) | ((u >> 1) << 8);
-    const bool colok = lane < 54 && s0 + 4 * lane < W;
-#pragma unroll
-    for (int e = 0; e < 2; ++e) {
-      const int qq = e ? 15 : 0;
-      const bool ok = colok && R0 + qq >= r0 && R0 + qq < rend;
-      const u64 mk = __ballot(ok);
-      const u32 pos = ((u32)(qhead + qcount) + mbcnt64(mk)) & (u32)(MX_NQ - 1);
-      lds16(lane_sel(mk, xbase + 2u * pos, dump)) = (unsigned short)(id0 | (u32)qq);
-      qcount += __popcll(mk);
-    }
-    if (MX_ABL & 1) { qhead = (qhead + qcount) & (MX_NQ - 1); qcount = 0; }
-    while (qcount > 0) nms_batch(min(qcount, 64), R0);
-    return dc;
-  };
-
-  // Dense mode: a block follows one that queued more than d_enter of its 864 groups (break-even of the two stages: ~345), and
-  // the blocks after it while at least d_leave of their 224 (lane, MFMA group) pairs hold a candidate (~78 % of the lanes <=>
-  // 35 % of the groups).  HC_OPT_FRONT_DENSE 1 / 0: every block / none (FrontParams::dense_enter < 0 / 0x7FFFFFFF).
-  const int d_enter = p.dense_enter < 0 ? -1 : p.dense_enter == 0x7FFFFFFF ? 0x7FFFFFFF : 400;
-  const int d_leave = p.dense_enter < 0 ? -1 : 170;
-  bool dense = p.dense_enter < 0, was_dense = false;
   // ---- the run: blocks of output rows R0 .. R0+15, R0 = r0 - 4 + 16 b ------------------------------------------------------
   const int nblocks = (rend - r0 + MX_LAG + MX_ROWS - 1) / MX_ROWS;
   const u32 prow = (u32)lane >> 2, ppart = (u32)lane & 3u;  // plane-tile / map-row stores: 4 lanes per row
@@ -672,13 +525,13 @@ __global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
         }
       }
     }
-    // zero the plane tiles; sparse mode: the map rows of the block are stored as zeros now, the few groups with strong pixels
-    // are overwritten by the batches (stores of one wave to one address keep their order)
+    // zero the plane tiles; the map rows of the block are stored as zeros now, the few groups with strong pixels are
+    // overwritten by the batches (stores of one wave to one address keep their order)
     lds128(tbase + 16u * (u32)lane) = v4i{ 0, 0, 0, 0 };
     const int orow = R0 + (int)prow;
     const bool orow_ok = orow >= r0 && orow < rend;
     if constexpr (PROV && !(MX_ABL & 4)) {
-      if (orow_ok && !dense) {
+      if (orow_ok) {
         uint8_t *pr = prov_frame + (u32)orow * p.prov_pitch + (u32)s0;
 #pragma unroll
         for (int k = 0; k < 7; ++k) {
@@ -688,34 +541,12 @@ __global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
       }
     }
     wave_lds_sync();
+    const bool edge_out = R0 < r0 || R0 + MX_ROWS > rend || s0 + MX_STRIP_W > W;
     if (!(MX_ABL & 8)) {
-      if (dense) {
-        const bool edge_d = R0 <= 0 || R0 + MX_ROWS >= H || strip == 0 || s0 + 225 > W;
-        was_dense = true;
-        dense = dense_phase(edge_d, R0) >= d_leave;
-      } else {
-        const bool edge_out = R0 < r0 || R0 + MX_ROWS > rend || s0 + MX_STRIP_W > W;
-        was_dense = false;
-        ecount = 0;
-        if (edge_out) sobel_phase(std::true_type{}, R0);
-        else sobel_phase(std::false_type{}, R0);
-        dense = ecount > d_enter;
-      }
+      if (edge_out) sobel_phase(std::true_type{}, R0);
+      else sobel_phase(std::false_type{}, R0);
     }
     wave_lds_sync();
-    if constexpr (PROV && !(MX_ABL & 4)) {
-      if (was_dense && orow_ok) {  // dense mode: the block's map rows from the STRONG tile, 54 dwords a row, 4 lanes a row
-#pragma unroll
-        for (int k = 0; k < 14; ++k) {
-          const u32 i = ppart + 4u * (u32)k;
-          if (i < 54u && s0 + 4 * (int)i < W) {
-            const u32 bit = 8u * psh + 4u * i;
-            const u32 nib = (lds32(tbase + prow * 32u + ((bit >> 5) << 2)) >> (bit & 31u)) & 15u;
-            *reinterpret_cast<gu32 *>(prov_frame + (u32)orow * p.prov_pitch + (u32)s0 + 4u * i) = nibble_to_bytes(nib);
-          }
-        }
-      }
-    }
     // the block's plane bytes: 16 rows x 27 bytes per plane
     if (!(MX_ABL & 4)) {
       auto put32 = [&](u32 r, u32 o) {

@@ -154,75 +154,3 @@ def test_mx_waves_per_workgroup(oracle, wpb):
         got = ctx.process(frames)
         _check(oracle, ctx, frames, got, tag=f"{wpb} waves per workgroup")
         assert ctx.front_waves_per_workgroup() == wpb
-
-
-# ---- the dense stage (blocks full of candidates: NMS in the MFMA's own layout) ------------------------------------------------
-def _dense_ctx(ctx, dense):
-    ctx.set_option(api.OPT_FRONT_MX, 1)
-    ctx.set_option(api.OPT_FRONT_DENSE, dense)
-    ctx.set_option(api.OPT_DEBUG_TAPS, 1)
-
-
-@pytest.mark.parametrize("name,img", list(_tap_images()), ids=[n for n, _ in _tap_images()])
-def test_mx_dense_taps(oracle, name, img):
-    """Every block through the dense stage (HC_OPT_FRONT_DENSE 1): every tap-test image -- borders, flat frames, the wrap
-    bands, 1 x 1 -- bit planes and maps equal the oracle's."""
-    h, w = img.shape
-    with api.Context(w, h, 1, 1) as ctx:
-        _dense_ctx(ctx, 1)
-        got = ctx.process(img)
-        _check(oracle, ctx, img[None], got, tag=f"dense, {name}")
-
-
-@pytest.mark.parametrize("dense", [1, -1])
-@pytest.mark.parametrize("w", [4, 28, 29, 215, 216, 217, 224, 226, 432, 640, 1000, 1920])
-def test_mx_dense_widths(oracle, w, dense):
-    """Widths around the strip and tile boundaries; dense for every block, and by the kernel's own rule on frames whose
-    blocks alternate between noise and flat / natural content (the modes switch inside a run)."""
-    h, n = 131, 3
-    frames = _frames(w, h, n, 900 + w)
-    if dense == -1:   # rows 32..95 of every frame: noise
-        frames[:, 32:96] = synth.noise(w, 64 * n, 5).reshape(n, 64, w)
-    with api.Context(w, h, 1, n) as ctx:
-        _dense_ctx(ctx, dense)
-        got = ctx.process(frames)
-        _check(oracle, ctx, frames, got, tag=f"dense {dense}, {w}x{h}")
-
-
-@pytest.mark.parametrize("h", [1, 2, 15, 16, 17, 33, 47, 130])
-def test_mx_dense_heights_and_runs(oracle, h):
-    w, n = 300, 2
-    frames = np.stack([synth.noise(w, h, 3 + h), synth.natural(w, h, 4 + h)])
-    for chunk in (0, 20):
-        for low, high, sat in ((10, 40, 0), (60, 200, 0), (25, 25, 1)):
-            with api.Context(w, h, 1, n) as ctx:
-                ctx.set_thresholds(low, high)
-                ctx.set_option(api.OPT_NMS_SATURATE, sat)
-                _dense_ctx(ctx, 1)
-                ctx.set_tuning(chunk, 0)
-                got = ctx.process(frames)
-                _check(oracle, ctx, frames, got, low, high, bool(sat), tag=f"dense, {w}x{h}, chunk {chunk}, {low}/{high}, saturate {sat}")
-
-
-@pytest.mark.parametrize("dense", [1, -1])
-def test_mx_dense_pipelined(oracle, dense):
-    """Pipelined mode: the dense blocks' rows of the provisional map come from the STRONG tile."""
-    import torch
-    w, h, nb = 640, 480, 4
-    runs = [np.stack([synth.noise(w, h, 50 + 4 * r + f) if (f + r) % 2 == 0 else synth.natural(w, h, 60 + 4 * r + f) for f in range(nb)]) for r in range(3)]
-    want = [oracle.canny_r_batch(b, 10, 40, threads=4) for b in runs]
-    d_in = [torch.from_numpy(b).cuda() for b in runs]
-    d_out = [torch.zeros((nb, h, w), dtype=torch.uint8, device="cuda") for _ in range(3)]
-    with api.Context(w, h, 1, nb) as ctx:
-        ctx.set_option(api.OPT_PIPELINE, 1)
-        ctx.set_option(api.OPT_FRONT_HALF, 0)
-        ctx.set_option(api.OPT_FRONT_MX, 1)
-        ctx.set_option(api.OPT_FRONT_DENSE, dense)
-        for r in range(3):
-            ctx.run_device(d_in[r].data_ptr(), w, w * h, d_out[r].data_ptr(), w, w * h, nb)
-        ctx.sync()
-        assert ctx.last_run_info() == (False, False, 5)
-        for r in range(3):
-            got = d_out[r].cpu().numpy()
-            for f in range(nb):
-                _diff(got[f], want[r][f], f"dense {dense}, pipelined, run {r}, frame {f}")
