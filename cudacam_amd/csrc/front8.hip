@@ -37,6 +37,10 @@
 #include "canny_device.h"
 #include <type_traits>
 
+#ifndef F8_ABL
+#define F8_ABL 0  // timing measurements with parts left out (tools/build_variant.sh, WRONG results): 1 no NMS batches, 2 no fix-up, 4 no phase 2 (Sobel, test, queue) and no batches
+#endif
+
 namespace hc {
 
 constexpr int F8_STRIP_W = 62 * 8;                 // 496 output columns per wave
@@ -629,6 +633,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
     wave_lds_sync();
     // the ring now holds input rows bw0-2 .. bw0+7 and `islot` is where bw0+8 will go, i.e. where the oldest, bw0-2, sits:
     // the chain of blur row bw0 + e starts at input row bw0 + e - 2, ring slot (islot + e) mod F8_RING
+    if (F8_ABL & 2) qn = 0;
     if (qn <= F8_FQ) {
 #pragma nounroll
       for (int base = 0; base < qn; base += 64) {
@@ -685,14 +690,18 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
       dense_window(bw0, (u32)sb);
     } else {
       wq = 0;
-      step(std::integral_constant<int, 0>{}, bw0 - 1, bq[0].x, bq[0].y);
-      step(std::integral_constant<int, 1>{}, bw0 + 0, bq[1].x, bq[1].y);
-      step(std::integral_constant<int, 2>{}, bw0 + 1, bq[2].x, bq[2].y);
-      while (qcount >= 64) nms_batch(64, bw0, (u32)sb);
-      step(std::integral_constant<int, 3>{}, bw0 + 2, bq[3].x, bq[3].y);
-      step(std::integral_constant<int, 4>{}, bw0 + 3, bq[4].x, bq[4].y);
-      step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
-      while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
+      if (!(F8_ABL & 4)) {
+        step(std::integral_constant<int, 0>{}, bw0 - 1, bq[0].x, bq[0].y);
+        step(std::integral_constant<int, 1>{}, bw0 + 0, bq[1].x, bq[1].y);
+        step(std::integral_constant<int, 2>{}, bw0 + 1, bq[2].x, bq[2].y);
+        if (F8_ABL & 1) { qhead = (qhead + qcount) & (F8_NQ - 1); qcount = 0; }
+        while (qcount >= 64) nms_batch(64, bw0, (u32)sb);
+        step(std::integral_constant<int, 3>{}, bw0 + 2, bq[3].x, bq[3].y);
+        step(std::integral_constant<int, 4>{}, bw0 + 3, bq[4].x, bq[4].y);
+        step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
+        if (F8_ABL & 1) { qhead = (qhead + qcount) & (F8_NQ - 1); qcount = 0; }
+        while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
+      }
     }
     wave_lds_sync();  // the next window's phase 1 overwrites the oldest ring rows
     if (IN == 2) __syncthreads();  // the three channels of this run stay within a window of each other (see above)
@@ -1012,14 +1021,18 @@ __global__ __launch_bounds__(256) void k_front8o(const FrontParams p)
       bs = bs < 0 ? bs + F8_RING : bs >= F8_RING ? bs - F8_RING : bs;
       bq[j] = *reinterpret_cast<const u32x2 *>(bring + bs * F8_ROW_BYTES + lane * 8);
     }
-    step(std::integral_constant<int, 0>{}, bw0 - 1, bq[0].x, bq[0].y);
-    step(std::integral_constant<int, 1>{}, bw0 + 0, bq[1].x, bq[1].y);
-    step(std::integral_constant<int, 2>{}, bw0 + 1, bq[2].x, bq[2].y);
-    while (qcount >= 64) nms_batch(64, bw0, (u32)sb);
-    step(std::integral_constant<int, 3>{}, bw0 + 2, bq[3].x, bq[3].y);
-    step(std::integral_constant<int, 4>{}, bw0 + 3, bq[4].x, bq[4].y);
-    step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
-    while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
+    if (!(F8_ABL & 4)) {
+      step(std::integral_constant<int, 0>{}, bw0 - 1, bq[0].x, bq[0].y);
+      step(std::integral_constant<int, 1>{}, bw0 + 0, bq[1].x, bq[1].y);
+      step(std::integral_constant<int, 2>{}, bw0 + 1, bq[2].x, bq[2].y);
+      if (F8_ABL & 1) { qhead = (qhead + qcount) & (F8_NQ - 1); qcount = 0; }
+      while (qcount >= 64) nms_batch(64, bw0, (u32)sb);
+      step(std::integral_constant<int, 3>{}, bw0 + 2, bq[3].x, bq[3].y);
+      step(std::integral_constant<int, 4>{}, bw0 + 3, bq[4].x, bq[4].y);
+      step(std::integral_constant<int, 5>{}, bw0 + 4, bq[5].x, bq[5].y);
+      if (F8_ABL & 1) { qhead = (qhead + qcount) & (F8_NQ - 1); qcount = 0; }
+      while (qcount > 0) nms_batch(min(qcount, 64), bw0, (u32)sb);
+    }
     wave_lds_sync();  // the next window overwrites the oldest ring rows
     bslot0 = bslot0 + F8_SUB >= F8_RING ? bslot0 + F8_SUB - F8_RING : bslot0 + F8_SUB;
   }
