@@ -344,6 +344,11 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
                 ctx.sync()
                 samples.append((kind, src[:ncheck].cpu().numpy(), d_out[:ncheck].cpu().numpy()))
             out["cpu_baseline"] = cpu_baseline(a, d_ins, samples)
+            if a.mode == "R":   # the closer stand-in for north_star's "host-core OpenCV cv::Canny baseline", at top level and labelled
+                om = out["cpu_baseline"]["other_mode"]
+                out["cpu_baseline_cv_canny_restatement"] = {"value": om["value"], "unit": om["unit"], "cores": om["cores"], "kind": "port",
+                                                            "sample": out["cpu_baseline"]["sample"],
+                                                            "note": "cv::Canny(img, 50, 150, 3, false) as restated in oracle/canny_oracle.c (Mode O): never compared with a real OpenCV (none on this host)"}
         if not brief and not a.no_host_fed and world == 1:
             out["host_fed"] = host_fed(a, d_in)
         print(json.dumps(out), flush=True)
