@@ -53,6 +53,7 @@ def parse():
     ap.add_argument("--out-buffers", type=int, default=0, help="pipelined mode: output buffers used in turn (a run into memory that an earlier, still unfinished run writes waits for that run); 0 = as many as the context keeps runs in flight: 2, or 4 for small batches")
     ap.add_argument("--front", default=None, choices=["front8", "split", "fused4"], help="front path (HC_OPT_FRONT_SPLIT): front8 = one kernel, 8 px per lane (default; Mode O: k_front8o); split = k_blur + k_nms; fused4 = the 4-px fused kernel (Mode O: both = k_front_o)")
     ap.add_argument("--mx", default="auto", choices=["auto", "never", "always"], help="k_front_mx (HC_OPT_FRONT_MX): the front path with blur and Sobel sums on the matrix pipe; auto = the library's default (never: opt-in)")
+    ap.add_argument("--slots", default="auto", choices=["auto", "2", "3"], help="pipelined big batches: output sets in flight (HC_OPT_PIPELINE_SLOTS): auto = two, a third on trial while the hysteresis chain bounds the step")
     ap.add_argument("--wpb", default="auto", choices=["auto", "1", "4"], help="waves per workgroup of the front kernel (HC_OPT_FRONT_WPB): auto = the library's run-time rule")
     ap.add_argument("--dense", default="auto", choices=["auto", "never", "always"], help="k_front8's dense path (HC_OPT_FRONT_DENSE): wave-wide NMS for windows full of candidates")
     ap.add_argument("--mode", default="R", choices=["R", "O"], help="R: reference-exact pipeline (default, the headline); O: cv::Canny semantics")
@@ -178,6 +179,8 @@ def run_config(a, torch, dist, world, rank, local, backend, brief):
     ctx.set_tuning(a.chunk, a.hyst_launches)
     if a.mx != "auto":
         ctx.set_option(api.OPT_FRONT_MX, {"never": 0, "always": 1}[a.mx])
+    if a.slots != "auto":
+        ctx.set_option(api.OPT_PIPELINE_SLOTS, int(a.slots))
     if a.wpb != "auto":
         ctx.set_option(api.OPT_FRONT_WPB, int(a.wpb))
     if a.dense != "auto":
