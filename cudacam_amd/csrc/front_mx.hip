@@ -52,7 +52,7 @@
 #include <type_traits>
 
 #ifndef MX_ABL
-#define MX_ABL 0  // timing experiments (tools/build_variant.sh, WRONG results): 1 no NMS batches, 2 no fix-up, 4 no stores, 8 no Sobel stage, 16 no blur stage, 32 no input loads
+#define MX_ABL 0  // timing experiments (tools/build_variant.sh, WRONG results): 1 no NMS batches, 2 no fix-up, 4 no stores, 8 no Sobel stage, 16 no blur stage, 32 no input loads, 64 no zero stores of the provisional map
 #endif
 
 namespace hc {
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
     lds128(tbase + 16u * (u32)lane) = v4i{ 0, 0, 0, 0 };
     const int orow = R0 + (int)prow;
     const bool orow_ok = orow >= r0 && orow < rend;
-    if constexpr (PROV && !(MX_ABL & 4)) {
+    if constexpr (PROV && !(MX_ABL & 4) && !(MX_ABL & 64)) {
       if (orow_ok) {
         uint8_t *pr = prov_frame + (u32)orow * p.prov_pitch + (u32)s0;
 #pragma unroll
