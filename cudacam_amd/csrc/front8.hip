@@ -38,7 +38,7 @@
 #include <type_traits>
 
 #ifndef F8_ABL
-#define F8_ABL 0  // timing measurements with parts left out (tools/build_variant.sh, WRONG results): 1 no NMS batches, 2 no fix-up, 4 no phase 2 (Sobel, test, queue) and no batches
+#define F8_ABL 0  // timing measurements with parts left out (tools/build_variant.sh, WRONG results): 1 no NMS batches, 2 no fix-up, 4 no phase 2 (Sobel, test, queue) and no batches, 8 no zero stores of the provisional map
 #endif
 
 namespace hc {
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void k_front8(const FrontParams p)
         gmem_u8 *pp = (gmem_u8 *)uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump_p);
         u32 o = prov_voff;
         asm volatile("" : "+v"(o));
-        *reinterpret_cast<gmem_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
+        if (!(F8_ABL & 8)) *reinterpret_cast<gmem_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
       }
     }
     // ids of the candidate half-lanes: a lane's two halves share an output byte -- if both are queued they sit in
@@ -852,7 +852,7 @@ __global__ __launch_bounds__(256) void k_front8o(const FrontParams p)
         gmem_u8 *pp = (gmem_u8 *)uniform_sel(valid, prov_frame + (u32)c * p.prov_pitch, p.dump_p);
         u32 o = prov_voff;
         asm volatile("" : "+v"(o));
-        *reinterpret_cast<gmem_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
+        if (!(F8_ABL & 8)) *reinterpret_cast<gmem_u32x2 *>(pp + o) = u32x2{ 0u, 0u };
       }
     }
     const u32 below = mbcnt64(mh0) + mbcnt64(mh1);

@@ -472,7 +472,9 @@ __global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
 
   // ---- the run: blocks of output rows R0 .. R0+15, R0 = r0 - 4 + 16 b ------------------------------------------------------
   const int nblocks = (rend - r0 + MX_LAG + MX_ROWS - 1) / MX_ROWS;
-  const u32 prow = (u32)lane >> 2, ppart = (u32)lane & 3u;  // plane-tile / map-row stores: 4 lanes per row
+  // zero stores of the map rows: the lane's byte offset from (row 2 k, column s0) and whether its group of 8 columns exists
+  const u32 zoff = (u32)(lane >> 5) * (PROV ? p.prov_pitch : 0u) + 8u * (u32)(lane & 31);
+  const bool zok = (lane & 31) < 27 && s0 + 8 * (lane & 31) < W;
   u32 xr[MX_ROWS];
   {  // input rows R0 .. R0+3 of the first block
     u32 x0[MX_LAG];
@@ -528,16 +530,15 @@ __global__ __launch_bounds__(64 * WPB, 3) void k_front_mx(const FrontParams p)
     // zero the plane tiles; the map rows of the block are stored as zeros now, the few groups with strong pixels are
     // overwritten by the batches (stores of one wave to one address keep their order)
     lds128(tbase + 16u * (u32)lane) = v4i{ 0, 0, 0, 0 };
-    const int orow = R0 + (int)prow;
-    const bool orow_ok = orow >= r0 && orow < rend;
     if constexpr (PROV && !(MX_ABL & 4) && !(MX_ABL & 64)) {
-      if (orow_ok) {
-        uint8_t *pr = prov_frame + (u32)orow * p.prov_pitch + (u32)s0;
+      // two rows per instruction: lanes 0..26 / 32..58 hold the 27 groups of 8 columns of row 2 k / 2 k + 1 -- 216 contiguous
+      // bytes per row.  (4 lanes per row, every instruction touching all 16 rows with 32 bytes each, cost 0.26 ms of the
+      // pipelined 2.4: profiles/r04/mx_ablation.txt)
 #pragma unroll
-        for (int k = 0; k < 7; ++k) {
-          const u32 i8 = ppart + 4u * (u32)k;  // 27 groups of 8 columns
-          if (i8 < 27u && s0 + 8 * (int)i8 < W) *reinterpret_cast<gu32x2 *>(pr + 8u * i8) = u32x2{ 0u, 0u };
-        }
+      for (int k = 0; k < 8; ++k) {
+        const int row = R0 + 2 * k + (lane >> 5);
+        if (zok && row >= r0 && row < rend)
+          *reinterpret_cast<gu32x2 *>(prov_frame + (u32)(R0 + 2 * k) * p.prov_pitch + (u32)s0 + zoff) = u32x2{ 0u, 0u };
       }
     }
     wave_lds_sync();

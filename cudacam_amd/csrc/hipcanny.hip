@@ -881,8 +881,8 @@ int run_impl(hc_ctx *c, const uint8_t *in, size_t in_pitch, size_t in_fs, uint8_
         const bool auto_one = c->nslot_use < NSLOT ? c->front_one : (long long)n_out * W * H >= 120ll * 1000 * 1000;
         fp.one_wave = (s.prov && !c->per_channel && (c->front_wpb_mode == 1 || (c->front_wpb_mode < 0 && auto_one))) ? 1 : 0;
         c->last_front_waves = c->per_channel ? 3 : fp.one_wave ? 1 : 4;
-        if (use_mx) {  // (its waves are independent too: HC_OPT_FRONT_WPB 1 / 0 picks one-wave / four-wave workgroups)
-          fp.one_wave = c->front_wpb_mode == 1 ? 1 : 0;
+        if (use_mx) {  // (its waves are independent too: one-wave workgroups beside the hysteresis, -3.5 % there, four-wave ones alone; HC_OPT_FRONT_WPB 1 / 4 fixes it)
+          fp.one_wave = (c->front_wpb_mode == 1 || (c->front_wpb_mode < 0 && s.prov)) ? 1 : 0;
           c->last_front_waves = fp.one_wave ? 1 : 4;
           HIPCK(launch_front_mx(fp, sf));
         }
