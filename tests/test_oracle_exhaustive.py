@@ -83,3 +83,40 @@ def test_quotient_by_24bit_multiply_all_sums():
     assert int(P.max()) < 2 ** 32
     assert np.array_equal(P >> np.uint64(24), S // np.uint64(159))
     assert np.array_equal(((P >> np.uint64(16)) & np.uint64(255)) == 0, S % np.uint64(159) == 0)
+
+
+def test_mx_biased_quotient_and_toeplitz_sums():
+    """k_front_mx (round 4) feeds the i8 MFMA with x ^ 0x80 (= x - 128 as a signed byte), so the matrix pipe returns
+    S' = S - 128 * 159; one v_mad_i32_i24 per pixel forms P = S' * 105518 + C0 with C0 = 20352 * 105518 + 2^31 (mod 2^32):
+    byte 3 of P is floor(S / 159) ^ 0x80 -- the blur byte in the ring's biased form -- and byte 2 is zero exactly when
+    S % 159 == 0, for every reachable S; both factors fit the signed 24-bit operands of the instruction.  And the banded
+    Toeplitz form itself: 5 row-times-matrix products with the A matrices of front_mx.hip (output column o <- window columns
+    o .. o + 4) give the 5 x 5 integer sums of a random 20 x 32 window exactly (numpy int64 in place of the MFMA's int32)."""
+    S = np.arange(0, 159 * 255 + 1, dtype=np.int64)
+    Sp = S - 128 * 159
+    assert Sp.min() >= -(1 << 23) and Sp.max() < (1 << 23) and 105518 < (1 << 23)
+    C0 = (20352 * 105518 + (1 << 31)) % (1 << 32)
+    P = (Sp * 105518 + C0) % (1 << 32)
+    assert np.array_equal(P, (S * 105518 + (1 << 31)) % (1 << 32))
+    assert np.array_equal((P >> 24) ^ 0x80, S // 159)
+    assert np.array_equal(((P >> 16) & 255) == 0, S % 159 == 0)
+    # the Toeplitz matrices (7 x 32 x 32: blur rows 0/4, 1/3, 2 of the kernel; the layout permutation of the rows is left out)
+    K = np.array([[2, 4, 5, 4, 2], [4, 9, 12, 9, 4], [5, 12, 15, 12, 5], [4, 9, 12, 9, 4], [2, 4, 5, 4, 2]], np.int64)
+    A = np.zeros((5, 28, 32), np.int64)
+    for i in range(5):
+        for o in range(28):
+            A[i, o, o:o + 5] = K[i]
+    rng = np.random.default_rng(5)
+    win = rng.integers(0, 256, (20, 32)).astype(np.int64)
+    xs = (win ^ 0x80).astype(np.int8).astype(np.int64)   # the bytes as the MFMA reads them
+    for r in range(16):
+        acc = sum(A[i] @ xs[r + i] for i in range(5))     # 28 sums S' of blur row r + 2
+        want = np.array([(K * win[r:r + 5, o:o + 5]).sum() for o in range(28)])
+        assert np.array_equal(acc + 128 * 159, want)
+    # the Sobel masks sum to zero: the bias drops out (cannyEdgeD.cu:158-167)
+    blur = rng.integers(0, 256, (3, 32)).astype(np.int64)
+    bs = (blur ^ 0x80).astype(np.int8).astype(np.int64)
+    for o in range(1, 31):
+        sx = lambda b: -b[0, o - 1] + b[0, o + 1] - 2 * b[1, o - 1] + 2 * b[1, o + 1] - b[2, o - 1] + b[2, o + 1]
+        sy = lambda b: b[0, o - 1] + 2 * b[0, o] + b[0, o + 1] - b[2, o - 1] - 2 * b[2, o] - b[2, o + 1]
+        assert sx(bs) == sx(blur) and sy(bs) == sy(blur)
