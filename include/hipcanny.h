@@ -250,9 +250,9 @@ int hc_set_tuning(hc_ctx *ctx, int chunk_rows, int hyst_launches);
  * columns, blocks of 16 rows), for every run that allows it (input pitch >= round_up(width, 4), height x pitch < 2^32;
  * pipelined mode: width % 8 == 0).  Same results bit for bit; hc_last_run_info reports form 5; HC_OPT_FRONT_WPB 1 / 4
  * picks its workgroup size.  Opt-in: measured on the MI355X (profiles/r04/mx_experiments.md) it takes 14 % less time than
- * k_front8 alone (1.83 against 2.14 ms per 1024 camera-like 1080p frames), the same time beside the hysteresis of the
- * batch before (2.4-2.55 against 2.5 ms), and half as much again on frames full of candidates (iid noise: 7.7 against
- * 5.1 ms), for which it has no dense path. */
+ * k_front8 alone (1.83 against 2.14 ms per 1024 camera-like 1080p frames), 3-5 % less beside the hysteresis of the batch
+ * before (2.37-2.43 against 2.50 ms), and half as much again on frames full of candidates (iid noise: 7.7 against 5.1 ms),
+ * for which it has no dense path. */
 enum { HC_OPT_NMS_SATURATE = 1, HC_OPT_PIPELINE = 2, HC_OPT_PER_CHANNEL = 3, HC_OPT_FRONT_SPLIT = 4, HC_OPT_L2_GRADIENT = 5, HC_OPT_DEBUG_TAPS = 6, HC_OPT_FRONT_HALF = 7,
        HC_OPT_FRONT_DENSE = 8, HC_OPT_COPY_STREAMS = 9, HC_OPT_PIPELINE_SLOTS = 10, HC_OPT_FRONT_WPB = 11, HC_OPT_FRONT_MX = 12,
        /* test and diagnostic hooks (the library reads no environment variables): hysteresis launches >= 1 on a fixed grid with
